@@ -1,0 +1,234 @@
+"""
+MCMC — drop-in for the reference sampler class (MCMC.py:4-544) with the hot loop on the GPU.
+
+`MCMC(model, data, dc_true, qpriors, qstart, nsamples, lstm_model, adapt_interval, verbose)` and
+`.sample(MAKE_ANIMATIONS)` keep the reference's signatures, return shapes and quirk modes
+(SURVEY Appendix A).  Each iteration — propose, box test, forward solve, sum of squares,
+accept/reject, inverse-gamma σ² update, adaptation — executes in the fused HIP kernel
+(rsf_mcmc_replay / rsf_mcmc_run); the host only feeds random variates.
+
+`sample()` draws those variates from the *global NumPy RNG in the reference's order*
+(MCMC.py:497, 331, 160 and the N unused normals of every RateStateModel.evaluate call,
+RateStateModel.py:392), so `np.random.seed(s)` selects the same chain the reference would run.
+`sample_batched()` (additive) runs many independent chains per launch with the on-device
+Philox stream and is the throughput path.
+"""
+import warnings
+
+import numpy as np
+
+from ._abi import ADAPT_MODES
+
+
+class PosteriorPool:
+    """Result of sample_batched: kept draws of every chain, iteration-major."""
+
+    def __init__(self, samples, std2, accept_rate, stats, nburn):
+        self.samples = samples          # (n_keep, C, d)
+        self.std2 = std2                # (n_keep, C)
+        self.accept_rate = accept_rate  # accepted / proposals over all chains
+        self.stats = stats
+        self.nburn = nburn
+
+    def pooled(self):
+        """(d, n_keep*C): every kept draw of every chain, the reference's (d, n) layout."""
+        n, C, d = self.samples.shape
+        return np.ascontiguousarray(self.samples.reshape(n * C, d).T)
+
+
+class MCMC:
+    def __init__(self, model, data, dc_true, qpriors, qstart, nsamples=100, lstm_model={}, adapt_interval=10,
+                 verbose=True):
+        self.model = model
+        self.qstart = qstart
+        self.qpriors = qpriors
+        self.nsamples = nsamples
+        self.nburn = int(nsamples / 2)
+        self.verbose = verbose
+        self.adapt_interval = adapt_interval
+        self.data = data
+        self.lstm_model = lstm_model
+        self.n0 = 0.01
+        self.qstart_limits = np.array([[self.qpriors[1], self.qpriors[2]]])
+        self.dc_true = dc_true
+        # additive: consume the N normals each reference forward solve wastes (RateStateModel.py:392)
+        self.replay_reference_rng = True
+
+    # ---- helpers ------------------------------------------------------------------------
+    def _engine(self):
+        if self.lstm_model:
+            raise NotImplementedError("the reduced-order-model hook (MCMC.py:124-125) has no implementation "
+                                      "in the reference either; pass a falsy lstm_model")
+        if not hasattr(self.model, "engine"):
+            raise TypeError("the HIP path integrates the rate-and-state model itself: `model` must be this "
+                            "package's RateStateModel (duck-typed Python models cannot run on the GPU)")
+        return self.model.engine()
+
+    def _prior_is_dict(self):
+        return hasattr(self.qpriors, "keys")
+
+    def _adapt_mode(self):
+        # list prior: update_covariance_matrix raises AttributeError, swallowed at MCMC.py:524-527 => never adapts
+        return "reference_dict" if self._prior_is_dict() else "none"
+
+    def _init_chains(self, eng, q0, seed=0, chain_offset=0, adapt_mode=None):
+        data = np.ascontiguousarray(self.data, dtype=np.float64).reshape(-1)
+        lo, hi = self.qstart_limits[:, 0], self.qstart_limits[:, 1]
+        eng.mcmc_init(q0, data, lo, hi, seed=seed, chain_offset=chain_offset, n0=self.n0,
+                      prior_len=len(self.qpriors), adapt_mode=adapt_mode or self._adapt_mode(),
+                      adapt_interval=self.adapt_interval)
+
+    # ---- reference sub-methods (public names kept) --------------------------------------
+    def evaluate_model(self):
+        if self.lstm_model:
+            raise NotImplementedError("reduced-order-model hook: no such class exists in the reference")
+        return self.model.evaluate()[1]
+
+    def SSqcalc(self, q_new):
+        """Sum of squares at q_new (d, 1) → (1, 1) (MCMC.py:381-387); one GPU forward solve."""
+        eng = self._engine()
+        self.model.Dc = q_new[0, ]
+        dc = float(np.asarray(self.model.Dc, dtype=np.float64).reshape(-1)[0])
+        ssq, _ = eng.forward([dc], data=np.asarray(self.data, dtype=np.float64).reshape(-1), want_ssq=True, want_acc=False)
+        return ssq.reshape(1, 1)
+
+    def acceptreject(self, q_new, SSqprev, std2):
+        condition1 = q_new > self.qstart_limits[:, 0]
+        condition2 = q_new < self.qstart_limits[:, 1]
+        accept = np.all(condition1 & condition2, axis=0)
+        SSqnew = None
+        if accept:
+            SSqnew = self.SSqcalc(q_new)
+            with np.errstate(all="ignore"):
+                accept_prob = np.clip(0.5 * (SSqprev - SSqnew) / std2, -np.inf, 0)
+                accept = accept_prob > np.log(np.random.rand(1))[0]
+        return accept, SSqnew if accept else SSqprev
+
+    def update_standard_deviation(self, SSqprev):
+        aval = 0.5 * (self.n0 + len(self.data))
+        bval = 0.5 * (self.n0 * self.std2[-1] + SSqprev)
+        self.std2.append(1 / (np.random.standard_gamma(aval) * (1 / bval)))  # == 1/gamma.rvs(aval, scale=1/bval)
+
+    def update_covariance_matrix(self, qparams):
+        Vnew = 2.38 ** 2 / len(self.qpriors.keys()) * np.cov(qparams[:, -self.adapt_interval:])
+        if qparams.shape[0] == 1:
+            Vnew = np.reshape(Vnew, (-1, 1))
+        return np.linalg.cholesky(Vnew).copy()
+
+    def compute_initial_covariance(self):
+        """std2[0] and Vstart (MCMC.py:244-266) from the device init kernel."""
+        eng = self._engine()
+        self._init_chains(eng, np.array([[float(self.qstart)]]))
+        _, _, std2, V = eng.get_state()
+        self.std2 = [float(std2[0])]
+        self.Vstart = V.reshape(1, 1).copy()
+        self.model.Dc = self.qstart * (1 + 1e-6)  # the reference leaves the model perturbed (MCMC.py:251)
+
+    # ---- the hot loop -------------------------------------------------------------------
+    def sample(self, MAKE_ANIMATIONS=False):
+        """One chain, nsamples proposals → ndarray (1, nsamples + 1 - nburn)  (MCMC.py:391-544)."""
+        eng = self._engine()
+        N = len(self.data)
+        burn = self.replay_reference_rng
+        self.compute_initial_covariance()
+        if burn:  # two solves in compute_initial_covariance + the initial SSqcalc
+            np.random.randn(N), np.random.randn(N), np.random.randn(N)
+        lo, hi = float(self.qstart_limits[0, 0]), float(self.qstart_limits[0, 1])
+        aval = 0.5 * (self.n0 + N)
+        qparams = np.empty((1, self.nsamples + 1))
+        qparams[0, 0] = self.qstart
+        std2 = list(self.std2)
+        iaccept = 0
+        for isample in range(self.nsamples):
+            q_cur, _, _, V = eng.get_state()
+            z = np.random.standard_normal()  # the single normal multivariate_normal consumes (MCMC.py:497)
+            with np.errstate(invalid="ignore"):
+                q_new = float(q_cur[0, 0]) + np.sqrt(float(V[0, 0, 0])) * z
+            u = 1.0
+            if q_new > lo and q_new < hi:  # the reference draws u only for in-bounds proposals
+                if burn:
+                    np.random.randn(N)
+                u = np.random.rand()
+            g = np.random.standard_gamma(aval)
+            tq, ts, ta = eng.mcmc_replay(np.array([[[z]]]), np.array([[u]]), np.array([[g]]))
+            accept = bool(ta[0, 0])
+            iaccept += accept
+            qparams[0, isample + 1] = tq[0, 0, 0]
+            std2.append(float(ts[0, 0]))
+            if self.verbose:
+                print(isample, accept)
+                print("Generated Sample ---- ", q_new)
+        if self.verbose:
+            print("acceptance ratio:", iaccept / self.nsamples)
+        self.std2 = np.asarray(std2)[self.nburn:]
+        self.acceptance_ratio = iaccept / self.nsamples
+        if MAKE_ANIMATIONS:
+            self._animate(qparams)
+        return qparams[:, self.nburn:]
+
+    def sample_batched(self, n_chains, seed=0, q0=None, jitter=None, n_iters=None, iters_per_launch=None,
+                       adapt_mode=None, mem="device", device=-1, chain_offset=0, keep="post_burn"):
+        """Throughput path (additive): n_chains independent chains, Philox variates on device.
+
+        q0: (C,) / (C, d) start points; default qstart for every chain, optionally jittered
+        uniformly in `jitter=(lo, hi)` with a NumPy generator seeded by `seed` and keyed by
+        global chain id.  Returns a PosteriorPool of the post-burn-in draws."""
+        from .engine import Engine
+
+        n_iters = self.nsamples if n_iters is None else n_iters
+        nburn = int(n_iters / 2) if keep == "post_burn" else 0
+        gids = chain_offset + np.arange(n_chains)
+        if q0 is None:
+            q0 = np.full((n_chains, 1), float(self.qstart))
+            if jitter is not None:
+                q0[:, 0] = [np.random.default_rng([seed, int(g)]).uniform(*jitter) for g in gids]
+        q0 = np.asarray(q0, dtype=np.float64).reshape(n_chains, -1)
+        eng = Engine(mem=mem, device=device)
+        try:
+            eng.set_model(self.model, getattr(self.model, "substeps", 1))
+            self._init_chains(eng, q0, seed=seed, chain_offset=chain_offset, adapt_mode=adapt_mode)
+            step = iters_per_launch or n_iters
+            kept_q, kept_s, done = [], [], 0
+            while done < n_iters:
+                n = min(step, n_iters - done)
+                tq, ts, _ = eng.mcmc_run(n, traces=("q", "std2"))
+                first = max(nburn - 1 - done, 0)  # trace row r is qparams column done + r + 1
+                if first < n:
+                    kept_q.append(tq[first:])
+                    kept_s.append(ts[first:])
+                done += n
+            eng.sync()
+            stats = eng.stats()
+            cat = (lambda xs: np.concatenate([np.asarray(x.cpu() if hasattr(x, "cpu") else x) for x in xs], axis=0))
+            samples, std2 = cat(kept_q), cat(kept_s)
+        finally:
+            eng.close()
+        rate = stats["accepted"] / max(1, n_iters * n_chains)
+        return PosteriorPool(samples, std2, rate, stats, nburn)
+
+    # ---- visualisation (off the hot path; degrades gracefully) --------------------------
+    def _animate(self, qparams):
+        try:
+            import matplotlib.pyplot as plt
+            from matplotlib.animation import FuncAnimation
+
+            fig, ax = plt.subplots()
+            (line,) = ax.plot([], [], lw=2)
+            ax.set_title(f"MCMC Sampling Evolution for dc = {self.dc_true:.2f} as True value")
+            ax.set_xlabel("Sample Index")
+            ax.set_ylabel("Sample Value")
+            ax.set_xlim(0, self.nsamples)
+            ax.set_ylim(np.min(qparams) - 1, np.max(qparams) + 1)
+
+            def update(frame):
+                line.set_data(np.arange(frame), qparams[0, :frame])
+                return (line,)
+
+            anim = FuncAnimation(fig, update, frames=self.nsamples, blit=True)
+            anim.save(f"mcmc_animation_dc_{self.dc_true:.2f}.mp4", fps=30, writer="ffmpeg")
+            plt.close(fig)
+        except Exception as ex:  # no ffmpeg / no display: the samples are still returned
+            warnings.warn(f"MCMC animation skipped: {ex}")
+
+
+assert set(ADAPT_MODES) == {"none", "reference_dict", "am"}

@@ -1,0 +1,131 @@
+"""
+RSF — drop-in for the reference driver class (RSF.py:59-1046): sweeps `dc_list`, makes the
+synthetic observation, round-trips it through the chosen persistence format and runs one
+MCMC per Dc.  The compute (forward solves, sampling) goes to the GPU; plotting stays optional
+host work and never blocks the result.
+
+Deviations from the reference, all needed for `main.py` to run at all:
+the JSON helpers are imported under their own names (the reference shadows them with the MySQL
+ones), the MySQL helpers are imported lazily, and a missing ffmpeg/display only skips figures.
+"""
+import time
+import warnings
+
+import numpy as np
+
+from . import json_save_load
+from .MCMC import MCMC
+
+
+def measure_execution_time(func):
+    """Wall-clock decorator; like the reference (RSF.py:49-54) it RETURNS the elapsed seconds."""
+
+    def wrapper(*args, **kwargs):
+        start_time = time.time()
+        func(*args, **kwargs)
+        return time.time() - start_time
+
+    return wrapper
+
+
+class RSF:
+    def __init__(self, number_slip_values=1, lowest_slip_value=1.0, largest_slip_value=1000.0, qstart=10.0,
+                 qpriors=["Uniform", 0.0, 10000.0], reduction=False, plotfigs=False):
+        self.num_dc = number_slip_values
+        self.dc_list = np.linspace(lowest_slip_value, largest_slip_value, self.num_dc)
+        self.num_features = 2
+        self.plotfigs = plotfigs
+        self.qstart = qstart
+        self.qpriors = qpriors
+        self.reduction = reduction
+        self.make_animations = True   # the reference hard-codes sample(True), RSF.py:897
+        self.verbose = True
+        self.posteriors = {}          # additive: dc -> kept samples of the last inference
+
+    def generate_time_series(self):
+        """Noisy acceleration for every Dc of dc_list, concatenated (RSF.py:355-371).  The
+        forward solves run as ONE batched launch; the noise is drawn per Dc in the reference's
+        order from the global NumPy RNG."""
+        n = self.model.num_tsteps
+        acc = self.model.evaluate_batch(self.dc_list)  # (num_dc, nout)
+        if acc.shape[1] != n:
+            raise ValueError(f"model produces {acc.shape[1]} samples per series, num_tsteps is {n}")
+        acc_appended_noise = np.zeros(len(self.dc_list) * n)
+        t = self.model.time_axis()
+        for index, dc_value in enumerate(self.dc_list):
+            self.model.Dc = dc_value
+            acc_noise = acc[index] + 1.0 * np.abs(acc[index]) * np.random.randn(n)  # RateStateModel.py:392
+            self.plot_time_series(t, acc[index])
+            acc_appended_noise[index * n:(index + 1) * n] = acc_noise
+        return acc_appended_noise
+
+    def plot_time_series(self, time, acceleration):
+        if not self.plotfigs:
+            return
+        try:
+            import matplotlib.pyplot as plt
+
+            plt.figure()
+            plt.title(f"$d_c$={self.model.Dc} $\\mu m$ RSF solution")
+            plt.plot(time, acceleration, linewidth=1.0, label="True")
+            plt.xlim(self.model.t_start - 2.0, self.model.t_final)
+            plt.xlabel("Time (sec)")
+            plt.ylabel("Acceleration $(\\mu m/s^2)$")
+            plt.grid(True)
+            plt.legend()
+        except Exception as ex:
+            warnings.warn(f"time-series figure skipped: {ex}")
+
+    def prepare_data(self, data):
+        if self.format == "json":
+            self.lstm_file = "model_lstm.json"
+            self.data_file = "data.json"
+            json_save_load.save_object(data, self.data_file)
+            data = json_save_load.load_object(self.data_file)
+        elif self.format == "mysql":
+            raise RuntimeError("the MySQL format needs a server and mysql.connector (RSF.py:597-602); "
+                               "neither is part of this build — use 'json'")
+        return data
+
+    def plot_dist(self, qparams, dc):
+        try:
+            import matplotlib.pyplot as plt
+            from scipy.stats import gaussian_kde
+
+            fig, axes = plt.subplots(1, 2, gridspec_kw={"width_ratios": [0.7, 0.15], "wspace": 0.15})
+            fig.suptitle(f"$d_c={dc:.2f}\\,\\mu m$ with {self.format} formatting", fontsize=10)
+            axes[0].plot(qparams[0, :], "b-", linewidth=1.0)
+            axes[0].set_ylabel("$d_c$", fontsize=10)
+            axes[0].set_xlabel("Sample number")
+            axes[0].set_xlim(0, qparams.shape[1])
+            grid = np.linspace(*axes[0].get_ylim(), 1000)
+            pdf = gaussian_kde(qparams[0, :]).pdf(grid)
+            axes[1].plot(pdf, grid, "b-", linewidth=1.0)
+            axes[1].fill_betweenx(grid, pdf, np.zeros(grid.shape), alpha=0.3)
+            axes[1].set_xlim(0, None)
+            axes[1].set_xlabel("Prob. density")
+            axes[1].get_yaxis().set_visible(False)
+            axes[1].get_xaxis().set_ticks([])
+        except Exception as ex:  # e.g. a chain that never moved makes the KDE singular
+            warnings.warn(f"posterior figure skipped: {ex}")
+
+    def perform_sampling_and_plotting(self, data, dc, nsamples, model_lstm):
+        index = np.where(self.dc_list == dc)[0][0] if dc in self.dc_list else -1
+        if index == -1:
+            print(f"Error: dc value {dc} not found in dc_list.")
+            return
+        start = index * self.model.num_tsteps
+        noisy_data = data[start:start + self.model.num_tsteps]
+        print(f"--- Dc is {dc} ---")
+        mc = MCMC(self.model, noisy_data, dc, self.qpriors, self.qstart, lstm_model=model_lstm, nsamples=nsamples,
+                  verbose=self.verbose)
+        qparams = mc.sample(self.make_animations)
+        self.posteriors[float(dc)] = qparams
+        self.plot_dist(qparams, dc)
+
+    @measure_execution_time
+    def inference(self, nsamples):
+        data = self.prepare_data(self.data)
+        for dc in self.dc_list:
+            self.perform_sampling_and_plotting(data, dc, nsamples, None)
+        return

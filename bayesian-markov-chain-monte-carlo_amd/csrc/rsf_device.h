@@ -1,0 +1,254 @@
+// rsf_device.h — device-side building blocks of the gfx950 kernels (included by rsf_hip.hip only).
+//
+//   Philox4x32-10 counter RNG + Box-Muller normals + Marsaglia-Tsang gamma   (K3)
+//   rate-and-state friction RHS and one classical RK4 step per lane           (K1 core)
+//   cooperative LDS staging of the chain-independent tables (loading V_l(t), observation)
+//
+// One lane integrates one chain; a wave64 is 64 independent chains.  The time recurrence is
+// sequential, so the sum of squares is a per-lane running sum; cross-lane work is confined to
+// the statistics counters (wave shuffle reduction) and LDS broadcast reads of the tables.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace rsf {
+
+// ---------------------------------------------------------------------------------------------
+// Kernel-argument blocks (wave-uniform → live in SGPRs)
+// ---------------------------------------------------------------------------------------------
+struct Consts {
+  double mu_ref, V_ref, k1, mu0;  // RateStateModel.py:167-180
+  double a_def, b_def;            // model.a / model.b where no per-lane value is given
+  double h, hh, h6;               // RK4 step, h/2, h/6
+  double inv_dt;                  // 1 / delta_t
+  const double *vl;               // V_l at stage times t_start + j*h/2, j = 0 .. 2*S*(nout-1)
+  const double *data;             // observation [nout] or nullptr
+  int32_t nout;                   // output samples (RateStateModel.py:358)
+  int32_t S;                      // RK4 steps per output interval
+  int32_t kc;                     // output intervals per LDS chunk
+  int32_t nchunks;                // ceil((nout-1)/kc); 1 => tables stay resident in LDS
+};
+
+// per-lane proposal constants, hoisted out of the time loop
+struct Lane {
+  double inv_dc;  // 1/Dc
+  double kprime;  // 1e-2*10/Dc, RateStateModel.py:324
+  double inv_a;   // 1/a
+  double b;
+};
+
+__device__ __forceinline__ Lane make_lane(double dc, double a, double b) {
+  Lane L;
+  L.inv_dc = 1.0 / dc;
+  L.kprime = (1e-2 * 10) / dc;
+  L.inv_a = 1.0 / a;
+  L.b = b;
+  return L;
+}
+
+// ---------------------------------------------------------------------------------------------
+// RHS, RateStateModel.py:318-355.  y[2] (V) never feeds back, so only (mu, theta) are inputs.
+// ---------------------------------------------------------------------------------------------
+template <bool DAMP>
+__device__ __forceinline__ void rhs(double mu, double th, double vl, const Lane &L, const Consts &K,
+                                    double &d0, double &d1, double &d2) {
+  const double lg = log(K.V_ref * th * L.inv_dc);
+  const double temp = L.inv_a * (mu - K.mu_ref - L.b * lg);
+  const double v = K.V_ref * exp(temp);
+  d1 = 1.0 - v * th * L.inv_dc;                // ageing law
+  d0 = L.kprime * (vl - v);                    // spring loading
+  const double bt = L.b / th * d1;
+  const double va = v * L.inv_a;
+  d2 = va * (d0 - bt);
+  if (DAMP) {                                  // one fixed-point pass, RateStateModel.py:349-353
+    d0 = d0 - K.k1 * d2;
+    d2 = va * (d0 - bt);
+  }
+}
+
+// one classical RK4 step of size h; vl0/vlm/vl1 = V_l at t, t+h/2, t+h
+template <bool DAMP>
+__device__ __forceinline__ void rk4_step(double &mu, double &th, double &V, double vl0, double vlm,
+                                         double vl1, const Lane &L, const Consts &K) {
+  double a0, a1, a2, b0, b1, b2, c0, c1, c2, e0, e1, e2;
+  rhs<DAMP>(mu, th, vl0, L, K, a0, a1, a2);
+  rhs<DAMP>(mu + K.hh * a0, th + K.hh * a1, vlm, L, K, b0, b1, b2);
+  rhs<DAMP>(mu + K.hh * b0, th + K.hh * b1, vlm, L, K, c0, c1, c2);
+  rhs<DAMP>(mu + K.h * c0, th + K.h * c1, vl1, L, K, e0, e1, e2);
+  mu = mu + K.h6 * (a0 + 2.0 * b0 + 2.0 * c0 + e0);
+  th = th + K.h6 * (a1 + 2.0 * b1 + 2.0 * c1 + e1);
+  V = V + K.h6 * (a2 + 2.0 * b2 + 2.0 * c2 + e2);
+}
+
+// ---------------------------------------------------------------------------------------------
+// LDS staging.  Chunk c covers output samples k0 .. k0+kn-1 (k0 = 1 + c*kc): it needs
+// 2*S*kn+1 loading values and kn observations.  Layout: [ vl : 2*S*kc+1 ][ data : kc ].
+// Every thread of the workgroup must call stage_chunk (it contains the barriers).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int lds_data_offset(const Consts &K) { return 2 * K.S * K.kc + 1; }
+
+__device__ __forceinline__ void stage_chunk(double *lds, const Consts &K, int k0, int kn) {
+  const int nv = 2 * K.S * kn + 1;
+  const int base = 2 * K.S * (k0 - 1);
+  __syncthreads();  // every wave is done with the previous chunk
+  for (int i = threadIdx.x; i < nv; i += blockDim.x) lds[i] = K.vl[base + i];
+  if (K.data) {
+    double *ld = lds + lds_data_offset(K);
+    for (int i = threadIdx.x; i < kn; i += blockDim.x) ld[i] = K.data[k0 + i];
+  }
+  __syncthreads();
+}
+
+// Integrate kn output intervals from the staged chunk.  Accumulates the sum of squares
+// (MCMC.py:387) and optionally stores acc time-major.  Called under the lane's activity mask.
+template <bool DAMP, bool WANT_SSQ, bool WANT_ACC>
+__device__ __forceinline__ void integrate_chunk(const double *lds, const Consts &K, const Lane &L, int k0,
+                                                int kn, double &mu, double &th, double &V, double &ssq,
+                                                double *acc_out, int64_t stride) {
+  const double *ld = lds + lds_data_offset(K);
+  int j = 0;
+  for (int kk = 0; kk < kn; ++kk) {
+    const double vprev = V;
+    for (int s = 0; s < K.S; ++s, j += 2) rk4_step<DAMP>(mu, th, V, lds[j], lds[j + 1], lds[j + 2], L, K);
+    const double ak = (V - vprev) * K.inv_dt;  // RateStateModel.py:388
+    if (WANT_ACC) acc_out[(int64_t)(k0 + kk) * stride] = ak;
+    if (WANT_SSQ) {
+      const double r = ak - ld[kk];
+      ssq += r * r;
+    }
+  }
+}
+
+// Full forward solve for one lane.  RESIDENT: the single chunk is already staged (no barriers,
+// so inactive lanes/waves may skip the call); otherwise all threads must call it.
+template <bool DAMP, bool WANT_SSQ, bool WANT_ACC, bool RESIDENT>
+__device__ __forceinline__ double solve(double *lds, const Consts &K, bool active, double dc, double a,
+                                        double b, double *acc_out, int64_t stride) {
+  const Lane L = make_lane(dc, a, b);
+  double mu = K.mu0, th = dc / K.V_ref, V = K.V_ref;  // RateStateModel.py:367-377
+  double ssq = 0.0;
+  if (WANT_SSQ && active) {
+    const double d0 = K.data[0];  // sample 0 belongs to no chunk: acc[0] = 0, RateStateModel.py:371
+    ssq = d0 * d0;
+  }
+  if (WANT_ACC && active) acc_out[0] = 0.0;
+  if (RESIDENT) {
+    if (active) integrate_chunk<DAMP, WANT_SSQ, WANT_ACC>(lds, K, L, 1, K.nout - 1, mu, th, V, ssq, acc_out, stride);
+  } else {
+    for (int k0 = 1; k0 < K.nout; k0 += K.kc) {
+      const int kn = min(K.kc, K.nout - k0);
+      stage_chunk(lds, K, k0, kn);
+      if (active) integrate_chunk<DAMP, WANT_SSQ, WANT_ACC>(lds, K, L, k0, kn, mu, th, V, ssq, acc_out, stride);
+    }
+  }
+  return ssq;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Philox4x32-10 (Salmon et al. SC'11; Random123 constants) and the variates built on it.
+// counter = (chain_lo, chain_hi, iteration, slot), key = seed.  Slots of one (chain, iteration):
+//   0: proposal normals z0,z1   1: z2   2: accept uniform   8+2j / 9+2j: gamma attempt j
+// ---------------------------------------------------------------------------------------------
+enum : uint32_t { SLOT_Z01 = 0, SLOT_Z2 = 1, SLOT_U = 2, SLOT_GAMMA = 8 };
+
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0,
+                                              uint32_t k1, uint32_t out[4]) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+    const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+    const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+    c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+__device__ __forceinline__ void draw_words(uint64_t seed, uint64_t chain, uint32_t iter, uint32_t slot,
+                                           uint32_t w[4]) {
+  philox4x32_10((uint32_t)chain, (uint32_t)(chain >> 32), iter, slot, (uint32_t)seed, (uint32_t)(seed >> 32), w);
+}
+
+// 53-bit uniform in (0, 1]
+__device__ __forceinline__ double u53(uint32_t hi, uint32_t lo) {
+  const uint64_t k = (((uint64_t)hi << 32) | lo) >> 11;
+  return (double)(k + 1) * 0x1.0p-53;
+}
+
+__device__ __forceinline__ void normal_pair(const uint32_t w[4], double &z0, double &z1) {
+  const double u1 = u53(w[0], w[1]), u2 = u53(w[2], w[3]);
+  const double r = sqrt(-2.0 * log(u1));
+  double s, c;
+  sincos(6.283185307179586476925286766559 * u2, &s, &c);
+  z0 = r * c;
+  z1 = r * s;
+}
+
+// Marsaglia & Tsang (2000), shape >= 1, log acceptance test only.
+__device__ __forceinline__ double gamma_draw(uint64_t seed, uint64_t chain, uint32_t iter, double shape) {
+  const double d = shape - 1.0 / 3.0;
+  const double c = 1.0 / sqrt(9.0 * d);
+  for (uint32_t j = 0; j < 64; ++j) {
+    uint32_t w[4];
+    double x, unused;
+    draw_words(seed, chain, iter, SLOT_GAMMA + 2 * j, w);
+    normal_pair(w, x, unused);
+    double v = 1.0 + c * x;
+    if (!(v > 0.0)) continue;
+    v = v * v * v;
+    draw_words(seed, chain, iter, SLOT_GAMMA + 2 * j + 1, w);
+    const double u = u53(w[0], w[1]);
+    if (log(u) < 0.5 * x * x + d * (1.0 - v + log(v))) return d * v;
+  }
+  return d;
+}
+
+// ---------------------------------------------------------------------------------------------
+// small dense helpers, fully unrolled on the compile-time dimension
+// ---------------------------------------------------------------------------------------------
+template <int D>
+__device__ __forceinline__ bool chol_lower(const double *V, double *L) {
+  bool ok = true;
+#pragma unroll
+  for (int e = 0; e < D * D; ++e) L[e] = 0.0;
+#pragma unroll
+  for (int j = 0; j < D; ++j) {
+    double s = V[j * D + j];
+#pragma unroll
+    for (int k = 0; k < j; ++k) s -= L[j * D + k] * L[j * D + k];
+    if (!(s > 0.0)) { ok = false; continue; }
+    const double ljj = sqrt(s);
+    L[j * D + j] = ljj;
+#pragma unroll
+    for (int i = j + 1; i < D; ++i) {
+      double t = V[i * D + j];
+#pragma unroll
+      for (int k = 0; k < j; ++k) t -= L[i * D + k] * L[j * D + k];
+      L[i * D + j] = t / ljj;
+    }
+  }
+  return ok;
+}
+
+template <int D>
+__device__ __forceinline__ void sym_inverse(const double *A, double *Ai) {
+  if (D == 1) {
+    Ai[0] = 1.0 / A[0];
+  } else {
+    const double c00 = A[4] * A[8] - A[5] * A[7], c01 = A[5] * A[6] - A[3] * A[8], c02 = A[3] * A[7] - A[4] * A[6];
+    const double id = 1.0 / (A[0] * c00 + A[1] * c01 + A[2] * c02);
+    Ai[0] = c00 * id; Ai[1] = (A[2] * A[7] - A[1] * A[8]) * id; Ai[2] = (A[1] * A[5] - A[2] * A[4]) * id;
+    Ai[3] = c01 * id; Ai[4] = (A[0] * A[8] - A[2] * A[6]) * id; Ai[5] = (A[2] * A[3] - A[0] * A[5]) * id;
+    Ai[6] = c02 * id; Ai[7] = (A[1] * A[6] - A[0] * A[7]) * id; Ai[8] = (A[0] * A[4] - A[1] * A[3]) * id;
+  }
+}
+
+// wave64 sum via DPP-free shuffles; result valid in lane 0
+__device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+
+}  // namespace rsf

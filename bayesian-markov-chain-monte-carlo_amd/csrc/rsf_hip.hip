@@ -1,0 +1,807 @@
+// rsf_hip.hip — gfx950 (MI355X / CDNA4) implementation of include/rsf_abi.h.
+//
+// Kernels (one lane = one chain, wave64 = 64 independent chains, fp64 VALU bound; no MFMA —
+// the path is an elementwise ODE recurrence plus per-lane reductions, not a contraction):
+//   forward_kernel  K1  batched RateStateModel.evaluate + SSq        (RateStateModel.py:188-395, MCMC.py:381-387)
+//   init_kernel     K4  compute_initial_covariance + initial SSq     (MCMC.py:244-266, 468)
+//   mcmc_kernel     K2  n_iters fused Metropolis iterations          (MCMC.py:494-527)
+//   probe_kernel    K3  Philox / variate self-test entry points
+// The chain-independent tables (loading velocity V_l at the RK4 stage times, observation) are
+// staged through LDS once per workgroup (or per chunk when they exceed the LDS budget) and
+// read as wave-wide broadcasts; per-chain state lives in registers for the whole launch and
+// touches HBM only at launch start/end plus one coalesced trace row per iteration.
+//
+// There is no host fallback in this file: every entry point either runs on the GPU or fails.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "../../include/rsf_abi.h"
+#include "rsf_device.h"
+
+using rsf::Consts;
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof g_err, fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                         \
+  do {                                                                                        \
+    hipError_t e_ = (expr);                                                                   \
+    if (e_ != hipSuccess) return fail(RSF_ERR_DEVICE, "%s -> %s", #expr, hipGetErrorString(e_)); \
+  } while (0)
+
+constexpr int kMaxBlock = 256;           // 4 waves: one per SIMD of a CU
+constexpr size_t kLdsBudget = 32 * 1024; // per workgroup; 4 workgroups/CU still fit in 160 KiB
+
+// ---------------------------------------------------------------------------------------------
+// kernels
+// ---------------------------------------------------------------------------------------------
+template <bool DAMP, bool WANT_SSQ, bool WANT_ACC>
+__global__ void __launch_bounds__(kMaxBlock)
+forward_kernel(Consts K, int64_t n, const double *__restrict__ dc, const double *__restrict__ a,
+               const double *__restrict__ b, double *__restrict__ ssq_out, double *__restrict__ acc_out) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool active = i < n;
+  const double dci = active ? dc[i] : 1.0;
+  const double ai = (active && a) ? a[i] : K.a_def;
+  const double bi = (active && b) ? b[i] : K.b_def;
+  double *acc_i = WANT_ACC ? acc_out + i : nullptr;
+  double ssq;
+  if (K.nchunks == 1) {
+    rsf::stage_chunk(lds, K, 1, K.nout - 1);
+    ssq = rsf::solve<DAMP, WANT_SSQ, WANT_ACC, true>(lds, K, active, dci, ai, bi, acc_i, n);
+  } else {
+    ssq = rsf::solve<DAMP, WANT_SSQ, WANT_ACC, false>(lds, K, active, dci, ai, bi, acc_i, n);
+  }
+  if (WANT_SSQ && active) ssq_out[i] = ssq;
+}
+
+struct InitArgs {
+  int64_t C;
+  double fd;       // forward-difference relative step, MCMC.py:251
+  double inv_dof;  // 1 / (nout - len(qpriors)), MCMC.py:261
+  const double *q0;
+  double *ssq, *std2, *V;
+};
+
+// Per chain: the unperturbed solve and one perturbed solve per parameter advance in lockstep in
+// one lane, so the sensitivity products X^T X accumulate without storing trajectories.
+template <int D, bool DAMP>
+__global__ void __launch_bounds__(kMaxBlock) init_kernel(Consts K, InitArgs A) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool active = i < A.C;
+  double p0[3] = {1.0, K.a_def, K.b_def};
+  if (active) {
+    p0[0] = A.q0[i * D];
+    if (D == 3) { p0[1] = A.q0[i * D + 1]; p0[2] = A.q0[i * D + 2]; }
+  }
+  rsf::Lane L[D + 1];
+  double mu[D + 1], th[D + 1], V[D + 1], inv_den[D];
+  L[0] = rsf::make_lane(p0[0], p0[1], p0[2]);
+  mu[0] = K.mu0; th[0] = p0[0] / K.V_ref; V[0] = K.V_ref;
+#pragma unroll
+  for (int p = 0; p < D; ++p) {
+    double pq[3] = {p0[0], p0[1], p0[2]};
+    pq[p] = pq[p] * (1 + A.fd);
+    inv_den[p] = 1.0 / (pq[p] * A.fd);  // perturbed value in the denominator, MCMC.py:264
+    L[p + 1] = rsf::make_lane(pq[0], pq[1], pq[2]);
+    mu[p + 1] = K.mu0; th[p + 1] = pq[0] / K.V_ref; V[p + 1] = K.V_ref;
+  }
+  double xtx[D * D];
+#pragma unroll
+  for (int e = 0; e < D * D; ++e) xtx[e] = 0.0;
+  double ssq = 0.0;
+  if (active) { const double d0 = K.data[0]; ssq = d0 * d0; }
+  const double *ld = lds + rsf::lds_data_offset(K);
+  for (int k0 = 1; k0 < K.nout; k0 += K.kc) {
+    const int kn = min(K.kc, K.nout - k0);
+    rsf::stage_chunk(lds, K, k0, kn);
+    if (!active) continue;
+    int j = 0;
+    for (int kk = 0; kk < kn; ++kk) {
+      double ak[D + 1];
+#pragma unroll
+      for (int t = 0; t <= D; ++t) ak[t] = V[t];
+      for (int s = 0; s < K.S; ++s, j += 2) {
+#pragma unroll
+        for (int t = 0; t <= D; ++t) rsf::rk4_step<DAMP>(mu[t], th[t], V[t], lds[j], lds[j + 1], lds[j + 2], L[t], K);
+      }
+#pragma unroll
+      for (int t = 0; t <= D; ++t) ak[t] = (V[t] - ak[t]) * K.inv_dt;
+      const double r = ak[0] - ld[kk];
+      ssq += r * r;
+      double x[D];
+#pragma unroll
+      for (int p = 0; p < D; ++p) x[p] = (ak[p + 1] - ak[0]) * inv_den[p];
+#pragma unroll
+      for (int p = 0; p < D; ++p)
+#pragma unroll
+        for (int r2 = 0; r2 < D; ++r2) xtx[p * D + r2] += x[p] * x[r2];
+    }
+  }
+  if (active) {
+    const double std2 = ssq * A.inv_dof;
+    double xi[D * D];
+    rsf::sym_inverse<D>(xtx, xi);
+#pragma unroll
+    for (int e = 0; e < D * D; ++e) A.V[i * D * D + e] = std2 * xi[e];  // MCMC.py:266
+    A.std2[i] = std2;
+    A.ssq[i] = ssq;
+  }
+}
+
+struct McmcArgs {
+  int64_t C, chain_offset, n_iters, iter_base;
+  uint64_t seed;
+  double n0, shape;
+  double lo[RSF_MAX_PARAMS], hi[RSF_MAX_PARAMS];
+  int32_t adapt_mode, adapt_interval;
+  double *q, *ssq, *std2, *V;           // per-chain state
+  double *wref, *wsum, *wsq;            // adaptation window (shifted sums)
+  int32_t *wn;
+  unsigned long long *stats;            // [3] accepted, evaluated, non-finite
+  const double *z, *u, *g;              // replay variates (REPLAY only)
+  double *tq, *ts;                      // traces, iteration-major
+  uint8_t *ta;
+};
+
+template <int D, bool DAMP, bool REPLAY>
+__global__ void __launch_bounds__(kMaxBlock) mcmc_kernel(Consts K, McmcArgs A) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool valid = i < A.C;
+  const uint64_t gid = (uint64_t)(A.chain_offset + i);  // RNG is keyed by the GLOBAL chain id
+  const bool resident = K.nchunks == 1;
+
+  double q[D], V[D * D];
+  double ssq = 0.0, std2 = 1.0;
+#pragma unroll
+  for (int p = 0; p < D; ++p) q[p] = 1.0;
+#pragma unroll
+  for (int e = 0; e < D * D; ++e) V[e] = 0.0;
+  double wr[D], ws[D], wq[D * D];
+  int32_t wn = 0;
+  if (valid) {
+#pragma unroll
+    for (int p = 0; p < D; ++p) q[p] = A.q[i * D + p];
+#pragma unroll
+    for (int e = 0; e < D * D; ++e) V[e] = A.V[i * D * D + e];
+    ssq = A.ssq[i];
+    std2 = A.std2[i];
+  }
+  if (A.adapt_mode != RSF_ADAPT_NONE && valid) {
+#pragma unroll
+    for (int p = 0; p < D; ++p) { wr[p] = A.wref[i * D + p]; ws[p] = A.wsum[i * D + p]; }
+#pragma unroll
+    for (int e = 0; e < D * D; ++e) wq[e] = A.wsq[i * D * D + e];
+    wn = A.wn[i];
+  }
+  uint32_t n_acc = 0, n_eval = 0, n_nonfinite = 0;
+
+  if (resident) rsf::stage_chunk(lds, K, 1, K.nout - 1);
+
+  for (int64_t n = 0; n < A.n_iters; ++n) {
+    const uint32_t it = (uint32_t)(A.iter_base + n);
+    const int64_t row = n * A.C + i;
+    // ---- proposal, MCMC.py:497 ----
+    double z[4] = {0.0, 0.0, 0.0, 0.0};
+    if (REPLAY) {
+      if (valid) {
+#pragma unroll
+        for (int p = 0; p < D; ++p) z[p] = A.z[row * D + p];
+      }
+    } else {
+      uint32_t w[4];
+      rsf::draw_words(A.seed, gid, it, rsf::SLOT_Z01, w);
+      rsf::normal_pair(w, z[0], z[1]);
+      if (D > 2) {
+        rsf::draw_words(A.seed, gid, it, rsf::SLOT_Z2, w);
+        rsf::normal_pair(w, z[2], z[3]);
+      }
+    }
+    double Lc[D * D], qn[D];
+    rsf::chol_lower<D>(V, Lc);
+    bool inb = valid;
+#pragma unroll
+    for (int p = 0; p < D; ++p) {
+      double s = q[p];
+#pragma unroll
+      for (int r = 0; r <= p; ++r) s += Lc[p * D + r] * z[r];
+      qn[p] = s;
+      inb = inb && (s > A.lo[p]) && (s < A.hi[p]);  // strict box, MCMC.py:318-320
+    }
+    // ---- likelihood: forward solve only for in-bounds proposals, MCMC.py:322-324 ----
+    const double an = D == 3 ? qn[1] : K.a_def, bn = D == 3 ? qn[2] : K.b_def;
+    double ssqn = 0.0;
+    if (resident) {
+      if (inb) ssqn = rsf::solve<DAMP, true, false, true>(lds, K, true, qn[0], an, bn, nullptr, 0);
+    } else {
+      ssqn = rsf::solve<DAMP, true, false, false>(lds, K, inb, qn[0], an, bn, nullptr, 0);
+    }
+    // ---- accept / reject, MCMC.py:327-333 ----
+    bool accept = false;
+    if (inb) {
+      double u;
+      if (REPLAY) {
+        u = A.u[row];
+      } else {
+        uint32_t w[4];
+        rsf::draw_words(A.seed, gid, it, rsf::SLOT_U, w);
+        u = rsf::u53(w[0], w[1]);
+      }
+      const double logalpha = fmin(0.5 * (ssq - ssqn) / std2, 0.0);
+      accept = logalpha > log(u);  // NaN compares false => reject
+      ++n_eval;
+      if (!isfinite(ssqn)) ++n_nonfinite;
+      if (accept) {
+        ssq = ssqn;
+#pragma unroll
+        for (int p = 0; p < D; ++p) q[p] = qn[p];
+        ++n_acc;
+      }
+    }
+    // ---- sigma^2 Gibbs update with the post-accept SSq, MCMC.py:158-160 ----
+    if (valid) {
+      const double bval = 0.5 * (A.n0 * std2 + ssq);
+      const double g = REPLAY ? A.g[row] : rsf::gamma_draw(A.seed, gid, it, A.shape);
+      std2 = bval / g;
+      if (A.tq) {
+#pragma unroll
+        for (int p = 0; p < D; ++p) A.tq[row * D + p] = q[p];
+      }
+      if (A.ts) A.ts[row] = std2;
+      if (A.ta) A.ta[row] = accept ? 1 : 0;
+    }
+    // ---- adaptation, MCMC.py:200-204, 523-527 ----
+    if (A.adapt_mode != RSF_ADAPT_NONE && valid) {
+#pragma unroll
+      for (int p = 0; p < D; ++p) {
+        ws[p] += q[p] - wr[p];
+#pragma unroll
+        for (int r = 0; r < D; ++r) wq[p * D + r] += (q[p] - wr[p]) * (q[r] - wr[r]);
+      }
+      ++wn;
+      if ((A.iter_base + n + 1) % A.adapt_interval == 0) {
+        if (wn >= 2) {
+          const double nn = (double)wn;
+          double Vn[D * D], Ln[D * D];
+          if (A.adapt_mode == RSF_ADAPT_REFERENCE_DICT) {
+            // d := len(qpriors.keys()) = 2, and the Cholesky FACTOR becomes the next covariance
+            Vn[0] = 2.38 * 2.38 / 2.0 * ((wq[0] - ws[0] * ws[0] / nn) / (nn - 1.0));
+            if (rsf::chol_lower<1>(Vn, Ln)) V[0] = Ln[0];
+          } else {
+#pragma unroll
+            for (int p = 0; p < D; ++p)
+#pragma unroll
+              for (int r = 0; r < D; ++r)
+                Vn[p * D + r] = 2.38 * 2.38 / (double)D * ((wq[p * D + r] - ws[p] * ws[r] / nn) / (nn - 1.0));
+            if (rsf::chol_lower<D>(Vn, Ln)) {
+#pragma unroll
+              for (int e = 0; e < D * D; ++e) V[e] = Vn[e];
+            }
+          }
+        }
+        wn = 0;
+#pragma unroll
+        for (int p = 0; p < D; ++p) { wr[p] = q[p]; ws[p] = 0.0; }
+#pragma unroll
+        for (int e = 0; e < D * D; ++e) wq[e] = 0.0;
+      }
+    }
+  }
+
+  if (valid) {
+#pragma unroll
+    for (int p = 0; p < D; ++p) A.q[i * D + p] = q[p];
+#pragma unroll
+    for (int e = 0; e < D * D; ++e) A.V[i * D * D + e] = V[e];
+    A.ssq[i] = ssq;
+    A.std2[i] = std2;
+    if (A.adapt_mode != RSF_ADAPT_NONE) {
+#pragma unroll
+      for (int p = 0; p < D; ++p) { A.wref[i * D + p] = wr[p]; A.wsum[i * D + p] = ws[p]; }
+#pragma unroll
+      for (int e = 0; e < D * D; ++e) A.wsq[i * D * D + e] = wq[e];
+      A.wn[i] = wn;
+    }
+  }
+  // statistics: wave shuffle reduction, one atomic per wave and counter
+  const unsigned long long s0 = rsf::wave_sum(n_acc), s1 = rsf::wave_sum(n_eval), s2 = rsf::wave_sum(n_nonfinite);
+  if ((threadIdx.x & 63) == 0) {
+    if (s0) atomicAdd(&A.stats[0], s0);
+    if (s1) atomicAdd(&A.stats[1], s1);
+    if (s2) atomicAdd(&A.stats[2], s2);
+  }
+}
+
+// out[0..3] = philox words (as doubles are not used here): layout documented at the call sites
+__global__ void probe_philox_kernel(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
+                                    uint32_t *out) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    uint32_t w[4];
+    rsf::philox4x32_10(c0, c1, c2, c3, k0, k1, w);
+    for (int j = 0; j < 4; ++j) out[j] = w[j];
+  }
+}
+
+// out = { z0, z1, z2, u, g }
+__global__ void probe_draws_kernel(uint64_t seed, uint64_t chain, uint32_t iter, int d, double shape, double *out) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    uint32_t w[4];
+    double z[4] = {0, 0, 0, 0};
+    rsf::draw_words(seed, chain, iter, rsf::SLOT_Z01, w);
+    rsf::normal_pair(w, z[0], z[1]);
+    if (d > 2) { rsf::draw_words(seed, chain, iter, rsf::SLOT_Z2, w); rsf::normal_pair(w, z[2], z[3]); }
+    rsf::draw_words(seed, chain, iter, rsf::SLOT_U, w);
+    out[0] = z[0]; out[1] = z[1]; out[2] = z[2];
+    out[3] = rsf::u53(w[0], w[1]);
+    out[4] = rsf::gamma_draw(seed, chain, iter, shape);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+struct DevBuf {
+  void *p = nullptr;
+  size_t cap = 0;
+};
+
+struct DeviceGuard {  // run on the ctx device, restore the caller's current device afterwards
+  int prev = -1;
+  bool ok = true;
+  explicit DeviceGuard(int dev) {
+    if (hipGetDevice(&prev) != hipSuccess) { ok = false; return; }
+    if (prev != dev && hipSetDevice(dev) != hipSuccess) ok = false;
+  }
+  ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
+}  // namespace
+
+struct rsf_ctx {
+  rsf_config cfg{};
+  int device = 0;
+  hipStream_t stream = nullptr;
+  int block = kMaxBlock;
+  // model
+  bool have_model = false;
+  rsf_model m{};
+  int32_t nout = 0;
+  double delta_t = 0, h = 0;
+  int32_t kc = 0, nchunks = 0;
+  size_t lds_bytes = 0;
+  DevBuf vl;
+  // chains
+  bool have_chains = false;
+  rsf_mcmc_config mc{};
+  DevBuf data, q, ssq, std2, V, wref, wsum, wsq, wn, stats;
+  int64_t iters_done = 0;
+  // staging for RSF_MEM_HOST callers
+  DevBuf stage[8];
+};
+
+namespace {
+
+int ensure(DevBuf &b, size_t bytes) {
+  if (bytes <= b.cap && b.p) return RSF_OK;
+  if (b.p) { HIP_TRY(hipFree(b.p)); b.p = nullptr; b.cap = 0; }
+  if (bytes == 0) bytes = 8;
+  HIP_TRY(hipMalloc(&b.p, bytes));
+  b.cap = bytes;
+  return RSF_OK;
+}
+
+void release(DevBuf &b) {
+  if (b.p) (void)hipFree(b.p);
+  b.p = nullptr;
+  b.cap = 0;
+}
+
+bool host_mem(const rsf_ctx *c) { return c->cfg.mem_space == RSF_MEM_HOST; }
+
+// input array: device pointer the kernels may read (staged copy for host callers)
+int stage_in(rsf_ctx *c, int slot, const void *src, size_t bytes, const void **dev) {
+  if (!src) { *dev = nullptr; return RSF_OK; }
+  if (!host_mem(c)) { *dev = src; return RSF_OK; }
+  int rc = ensure(c->stage[slot], bytes);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(c->stage[slot].p, src, bytes, hipMemcpyHostToDevice, c->stream));
+  *dev = c->stage[slot].p;
+  return RSF_OK;
+}
+
+// output array: device pointer the kernels may write
+int stage_out(rsf_ctx *c, int slot, void *dst, size_t bytes, void **dev) {
+  if (!dst) { *dev = nullptr; return RSF_OK; }
+  if (!host_mem(c)) { *dev = dst; return RSF_OK; }
+  int rc = ensure(c->stage[slot], bytes);
+  if (rc) return rc;
+  *dev = c->stage[slot].p;
+  return RSF_OK;
+}
+
+int copy_back(rsf_ctx *c, int slot, void *dst, size_t bytes) {
+  if (!dst || !host_mem(c)) return RSF_OK;
+  HIP_TRY(hipMemcpyAsync(dst, c->stage[slot].p, bytes, hipMemcpyDeviceToHost, c->stream));
+  return RSF_OK;
+}
+
+int finish(rsf_ctx *c) {  // host callers get synchronous semantics
+  HIP_TRY(hipGetLastError());
+  if (host_mem(c)) HIP_TRY(hipStreamSynchronize(c->stream));
+  return RSF_OK;
+}
+
+Consts make_consts(const rsf_ctx *c, const double *data) {
+  Consts K{};
+  K.mu_ref = c->m.mu_ref; K.V_ref = c->m.V_ref; K.k1 = c->m.k1; K.mu0 = c->m.mu_t_zero;
+  K.a_def = c->m.a; K.b_def = c->m.b;
+  K.h = c->h; K.hh = 0.5 * c->h; K.h6 = c->h / 6.0;
+  K.inv_dt = 1.0 / c->delta_t;
+  K.vl = (const double *)c->vl.p;
+  K.data = data;
+  K.nout = c->nout; K.S = c->m.substeps; K.kc = c->kc; K.nchunks = c->nchunks;
+  return K;
+}
+
+unsigned grid_for(const rsf_ctx *c, int64_t n) { return (unsigned)((n + c->block - 1) / c->block); }
+
+template <int D, bool DAMP>
+int launch_mcmc(rsf_ctx *c, const Consts &K, const McmcArgs &A, bool replay) {
+  const dim3 grid(grid_for(c, A.C)), block(c->block);
+  if (replay)
+    hipLaunchKernelGGL((mcmc_kernel<D, DAMP, true>), grid, block, c->lds_bytes, c->stream, K, A);
+  else
+    hipLaunchKernelGGL((mcmc_kernel<D, DAMP, false>), grid, block, c->lds_bytes, c->stream, K, A);
+  return RSF_OK;
+}
+
+int run_mcmc(rsf_ctx *c, int64_t n_iters, const double *z, const double *u, const double *g, double *tq,
+             double *ts, uint8_t *ta, bool replay) {
+  if (!c || n_iters < 0) return fail(RSF_ERR_INVALID, "rsf_mcmc_run: bad argument");
+  if (!c->have_chains) return fail(RSF_ERR_STATE, "rsf_mcmc_run: call rsf_mcmc_init first");
+  if (n_iters == 0) return RSF_OK;
+  DeviceGuard guard(c->device);
+  if (!guard.ok) return fail(RSF_ERR_DEVICE, "rsf_mcmc_run: cannot select device %d", c->device);
+  const int d = c->mc.n_params;
+  const int64_t C = c->mc.n_chains;
+  const size_t rows = (size_t)n_iters * (size_t)C;
+  McmcArgs A{};
+  A.C = C; A.chain_offset = c->mc.chain_offset; A.n_iters = n_iters; A.iter_base = c->iters_done;
+  A.seed = c->mc.seed; A.n0 = c->mc.n0; A.shape = 0.5 * (c->mc.n0 + (double)c->nout);  // MCMC.py:158
+  for (int p = 0; p < RSF_MAX_PARAMS; ++p) { A.lo[p] = c->mc.lo[p]; A.hi[p] = c->mc.hi[p]; }
+  A.adapt_mode = c->mc.adapt_mode; A.adapt_interval = c->mc.adapt_interval > 0 ? c->mc.adapt_interval : 1;
+  A.q = (double *)c->q.p; A.ssq = (double *)c->ssq.p; A.std2 = (double *)c->std2.p; A.V = (double *)c->V.p;
+  A.wref = (double *)c->wref.p; A.wsum = (double *)c->wsum.p; A.wsq = (double *)c->wsq.p; A.wn = (int32_t *)c->wn.p;
+  A.stats = (unsigned long long *)c->stats.p;
+  int rc;
+  const void *dz = nullptr, *du = nullptr, *dg = nullptr;
+  void *dtq = nullptr, *dts = nullptr, *dta = nullptr;
+  if ((rc = stage_in(c, 0, z, rows * d * sizeof(double), &dz))) return rc;
+  if ((rc = stage_in(c, 1, u, rows * sizeof(double), &du))) return rc;
+  if ((rc = stage_in(c, 2, g, rows * sizeof(double), &dg))) return rc;
+  if ((rc = stage_out(c, 3, tq, rows * d * sizeof(double), &dtq))) return rc;
+  if ((rc = stage_out(c, 4, ts, rows * sizeof(double), &dts))) return rc;
+  if ((rc = stage_out(c, 5, ta, rows, &dta))) return rc;
+  A.z = (const double *)dz; A.u = (const double *)du; A.g = (const double *)dg;
+  A.tq = (double *)dtq; A.ts = (double *)dts; A.ta = (uint8_t *)dta;
+  const Consts K = make_consts(c, (const double *)c->data.p);
+  const bool damp = c->m.flags & RSF_FLAG_RADIATION_DAMPING;
+  if (d == 1) rc = damp ? launch_mcmc<1, true>(c, K, A, replay) : launch_mcmc<1, false>(c, K, A, replay);
+  else rc = damp ? launch_mcmc<3, true>(c, K, A, replay) : launch_mcmc<3, false>(c, K, A, replay);
+  if (rc) return rc;
+  if ((rc = copy_back(c, 3, tq, rows * d * sizeof(double)))) return rc;
+  if ((rc = copy_back(c, 4, ts, rows * sizeof(double)))) return rc;
+  if ((rc = copy_back(c, 5, ta, rows))) return rc;
+  c->iters_done += n_iters;
+  return finish(c);
+}
+
+void free_chains(rsf_ctx *c) {
+  release(c->data); release(c->q); release(c->ssq); release(c->std2); release(c->V);
+  release(c->wref); release(c->wsum); release(c->wsq); release(c->wn); release(c->stats);
+  c->have_chains = false;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------------
+extern "C" {
+
+int rsf_version(void) { return RSF_ABI_VERSION; }
+const char *rsf_backend(void) { return "hip-gfx950"; }
+const char *rsf_last_error(void) { return g_err; }
+
+int rsf_device_count(void) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) { fail(RSF_ERR_DEVICE, "hipGetDeviceCount -> %s", hipGetErrorString(e)); return 0; }
+  return n;
+}
+
+int rsf_create(const rsf_config *cfg, rsf_ctx **out) {
+  if (!cfg || !out) return fail(RSF_ERR_INVALID, "rsf_create: NULL argument");
+  if (cfg->size != sizeof(rsf_config) || cfg->version != RSF_ABI_VERSION)
+    return fail(RSF_ERR_INVALID, "rsf_create: config size/version mismatch");
+  if (cfg->mem_space != RSF_MEM_HOST && cfg->mem_space != RSF_MEM_DEVICE)
+    return fail(RSF_ERR_INVALID, "rsf_create: bad mem_space");
+  int block = cfg->block_threads ? (int)cfg->block_threads : kMaxBlock;
+  if (block % 64 != 0 || block < 64 || block > kMaxBlock)
+    return fail(RSF_ERR_INVALID, "rsf_create: block_threads must be a multiple of 64 in [64, %d]", kMaxBlock);
+  int n = 0;
+  HIP_TRY(hipGetDeviceCount(&n));
+  if (n <= 0) return fail(RSF_ERR_DEVICE, "rsf_create: no HIP device visible (this library has no CPU fallback)");
+  int dev = cfg->device;
+  if (dev < 0) HIP_TRY(hipGetDevice(&dev));
+  if (dev >= n) return fail(RSF_ERR_INVALID, "rsf_create: device %d out of range (%d visible)", dev, n);
+  rsf_ctx *c = new (std::nothrow) rsf_ctx();
+  if (!c) return fail(RSF_ERR_NOMEM, "rsf_create: out of memory");
+  c->cfg = *cfg;
+  c->device = dev;
+  c->stream = (hipStream_t)cfg->stream;  // NULL = the device's default stream
+  c->block = block;
+  *out = c;
+  return RSF_OK;
+}
+
+int rsf_destroy(rsf_ctx *c) {
+  if (!c) return RSF_OK;
+  {
+    DeviceGuard guard(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    free_chains(c);
+    release(c->vl);
+    for (auto &s : c->stage) release(s);
+  }
+  delete c;
+  return RSF_OK;
+}
+
+int rsf_sync(rsf_ctx *c) {
+  if (!c) return fail(RSF_ERR_INVALID, "rsf_sync: NULL ctx");
+  DeviceGuard guard(c->device);
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return RSF_OK;
+}
+
+int rsf_set_model(rsf_ctx *c, const rsf_model *m) {
+  if (!c || !m) return fail(RSF_ERR_INVALID, "rsf_set_model: NULL argument");
+  if (m->size != sizeof(rsf_model)) return fail(RSF_ERR_INVALID, "rsf_set_model: struct size mismatch");
+  if (m->nsteps < 2 || m->substeps < 1 || !(m->t_final > m->t_start))
+    return fail(RSF_ERR_INVALID, "rsf_set_model: need nsteps >= 2, substeps >= 1, t_final > t_start");
+  DeviceGuard guard(c->device);
+  if (!guard.ok) return fail(RSF_ERR_DEVICE, "rsf_set_model: cannot select device %d", c->device);
+  const double delta_t = (m->t_final - m->t_start) / m->nsteps;                  // RateStateModel.py:176
+  const int32_t nout = (int32_t)std::floor((m->t_final - m->t_start) / delta_t); // RateStateModel.py:358
+  if (nout < 2) return fail(RSF_ERR_INVALID, "rsf_set_model: fewer than 2 output samples");
+  const int S = m->substeps;
+  const double h = delta_t / S, hh = 0.5 * h;
+  // LDS chunking: kc output intervals need (2*S*kc + 1) loading values + kc observations
+  const size_t words = kLdsBudget / sizeof(double);
+  int64_t kc = ((int64_t)words - 1) / (2 * (int64_t)S + 1);
+  if (kc < 1) return fail(RSF_ERR_UNSUPPORTED, "rsf_set_model: substeps=%d does not fit the LDS staging budget", S);
+  if (kc > nout - 1) kc = nout - 1;
+  // chain-independent loading velocity at every RK4 stage time, RateStateModel.py:327-329
+  const size_t nvl = 2 * (size_t)S * (size_t)(nout - 1) + 1;
+  std::vector<double> vl(nvl);
+  for (size_t j = 0; j < nvl; ++j) {
+    const double t = m->t_start + (double)j * hh;
+    vl[j] = m->V_ref * (1 + std::exp(-t / 20) * std::sin(10 * t));
+  }
+  int rc = ensure(c->vl, nvl * sizeof(double));
+  if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(c->vl.p, vl.data(), nvl * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));  // vl (host vector) goes out of scope
+  if (c->have_chains && nout != c->nout) free_chains(c);  // observation length changed
+  c->m = *m;
+  c->delta_t = delta_t; c->h = h; c->nout = nout;
+  c->kc = (int32_t)kc;
+  c->nchunks = (int32_t)((nout - 1 + kc - 1) / kc);
+  c->lds_bytes = (size_t)(2 * S * kc + 1 + kc) * sizeof(double);
+  c->have_model = true;
+  return RSF_OK;
+}
+
+int rsf_model_nout(rsf_ctx *c, int32_t *nout) {
+  if (!c || !nout) return fail(RSF_ERR_INVALID, "rsf_model_nout: NULL argument");
+  if (!c->have_model) return fail(RSF_ERR_STATE, "rsf_model_nout: call rsf_set_model first");
+  *nout = c->nout;
+  return RSF_OK;
+}
+
+int rsf_forward_batch(rsf_ctx *c, int64_t n, const double *dc, const double *a, const double *b,
+                      const double *data, double *ssq_out, double *acc_out) {
+  if (!c || !dc || n < 0) return fail(RSF_ERR_INVALID, "rsf_forward_batch: bad argument");
+  if (!c->have_model) return fail(RSF_ERR_STATE, "rsf_forward_batch: call rsf_set_model first");
+  if (ssq_out && !data) return fail(RSF_ERR_INVALID, "rsf_forward_batch: ssq_out needs data");
+  if (n == 0) return RSF_OK;
+  DeviceGuard guard(c->device);
+  if (!guard.ok) return fail(RSF_ERR_DEVICE, "rsf_forward_batch: cannot select device %d", c->device);
+  const size_t nb = (size_t)n * sizeof(double);
+  const void *ddc, *da, *db, *ddata;
+  void *dssq, *dacc;
+  int rc;
+  if ((rc = stage_in(c, 0, dc, nb, &ddc))) return rc;
+  if ((rc = stage_in(c, 1, a, nb, &da))) return rc;
+  if ((rc = stage_in(c, 2, b, nb, &db))) return rc;
+  if ((rc = stage_in(c, 3, ssq_out ? data : nullptr, (size_t)c->nout * sizeof(double), &ddata))) return rc;
+  if ((rc = stage_out(c, 4, ssq_out, nb, &dssq))) return rc;
+  if ((rc = stage_out(c, 5, acc_out, nb * (size_t)c->nout, &dacc))) return rc;
+  const Consts K = make_consts(c, (const double *)ddata);
+  const dim3 grid(grid_for(c, n)), block(c->block);
+  const bool damp = c->m.flags & RSF_FLAG_RADIATION_DAMPING;
+#define RSF_LAUNCH_FWD(DAMP, SSQ, ACC)                                                                 \
+  hipLaunchKernelGGL((forward_kernel<DAMP, SSQ, ACC>), grid, block, c->lds_bytes, c->stream, K, n,     \
+                     (const double *)ddc, (const double *)da, (const double *)db, (double *)dssq, (double *)dacc)
+  const int sel = (damp ? 4 : 0) | (ssq_out ? 2 : 0) | (acc_out ? 1 : 0);
+  switch (sel) {
+    case 0: case 4: break;  // nothing requested
+    case 1: RSF_LAUNCH_FWD(false, false, true); break;
+    case 2: RSF_LAUNCH_FWD(false, true, false); break;
+    case 3: RSF_LAUNCH_FWD(false, true, true); break;
+    case 5: RSF_LAUNCH_FWD(true, false, true); break;
+    case 6: RSF_LAUNCH_FWD(true, true, false); break;
+    case 7: RSF_LAUNCH_FWD(true, true, true); break;
+  }
+#undef RSF_LAUNCH_FWD
+  if ((rc = copy_back(c, 4, ssq_out, nb))) return rc;
+  if ((rc = copy_back(c, 5, acc_out, nb * (size_t)c->nout))) return rc;
+  return finish(c);
+}
+
+int rsf_mcmc_init(rsf_ctx *c, const rsf_mcmc_config *cfg, const double *q0, const double *data) {
+  if (!c || !cfg || !q0 || !data) return fail(RSF_ERR_INVALID, "rsf_mcmc_init: NULL argument");
+  if (!c->have_model) return fail(RSF_ERR_STATE, "rsf_mcmc_init: call rsf_set_model first");
+  if (cfg->size != sizeof(rsf_mcmc_config)) return fail(RSF_ERR_INVALID, "rsf_mcmc_init: struct size mismatch");
+  if (cfg->n_params != 1 && cfg->n_params != 3) return fail(RSF_ERR_UNSUPPORTED, "rsf_mcmc_init: n_params must be 1 or 3");
+  if (cfg->n_chains < 1) return fail(RSF_ERR_INVALID, "rsf_mcmc_init: n_chains < 1");
+  if (cfg->adapt_mode == RSF_ADAPT_REFERENCE_DICT && cfg->n_params != 1)
+    return fail(RSF_ERR_UNSUPPORTED, "rsf_mcmc_init: reference_dict adaptation is defined for 1 parameter only");
+  if (cfg->adapt_mode < 0 || cfg->adapt_mode > RSF_ADAPT_AM || (cfg->adapt_mode && cfg->adapt_interval < 2))
+    return fail(RSF_ERR_INVALID, "rsf_mcmc_init: bad adapt_mode / adapt_interval");
+  DeviceGuard guard(c->device);
+  if (!guard.ok) return fail(RSF_ERR_DEVICE, "rsf_mcmc_init: cannot select device %d", c->device);
+  const int d = cfg->n_params;
+  const int64_t C = cfg->n_chains;
+  const size_t cb = (size_t)C * sizeof(double);
+  int rc;
+  if ((rc = ensure(c->data, (size_t)c->nout * sizeof(double)))) return rc;
+  if ((rc = ensure(c->q, cb * d))) return rc;
+  if ((rc = ensure(c->ssq, cb))) return rc;
+  if ((rc = ensure(c->std2, cb))) return rc;
+  if ((rc = ensure(c->V, cb * d * d))) return rc;
+  if ((rc = ensure(c->wref, cb * d))) return rc;
+  if ((rc = ensure(c->wsum, cb * d))) return rc;
+  if ((rc = ensure(c->wsq, cb * d * d))) return rc;
+  if ((rc = ensure(c->wn, (size_t)C * sizeof(int32_t)))) return rc;
+  if ((rc = ensure(c->stats, 3 * sizeof(unsigned long long)))) return rc;
+  const hipMemcpyKind kind = host_mem(c) ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
+  HIP_TRY(hipMemcpyAsync(c->data.p, data, (size_t)c->nout * sizeof(double), kind, c->stream));
+  HIP_TRY(hipMemcpyAsync(c->q.p, q0, cb * d, kind, c->stream));
+  HIP_TRY(hipMemcpyAsync(c->wref.p, q0, cb * d, kind, c->stream));
+  HIP_TRY(hipMemsetAsync(c->wsum.p, 0, cb * d, c->stream));
+  HIP_TRY(hipMemsetAsync(c->wsq.p, 0, cb * d * d, c->stream));
+  HIP_TRY(hipMemsetAsync(c->wn.p, 0, (size_t)C * sizeof(int32_t), c->stream));
+  HIP_TRY(hipMemsetAsync(c->stats.p, 0, 3 * sizeof(unsigned long long), c->stream));
+  InitArgs A{};
+  A.C = C;
+  A.fd = cfg->fd_rel_step;
+  A.inv_dof = 1.0 / (double)(c->nout - (cfg->prior_len ? cfg->prior_len : d));
+  A.q0 = (const double *)c->q.p;
+  A.ssq = (double *)c->ssq.p; A.std2 = (double *)c->std2.p; A.V = (double *)c->V.p;
+  const Consts K = make_consts(c, (const double *)c->data.p);
+  const dim3 grid(grid_for(c, C)), block(c->block);
+  const bool damp = c->m.flags & RSF_FLAG_RADIATION_DAMPING;
+  if (d == 1) {
+    if (damp) hipLaunchKernelGGL((init_kernel<1, true>), grid, block, c->lds_bytes, c->stream, K, A);
+    else hipLaunchKernelGGL((init_kernel<1, false>), grid, block, c->lds_bytes, c->stream, K, A);
+  } else {
+    if (damp) hipLaunchKernelGGL((init_kernel<3, true>), grid, block, c->lds_bytes, c->stream, K, A);
+    else hipLaunchKernelGGL((init_kernel<3, false>), grid, block, c->lds_bytes, c->stream, K, A);
+  }
+  c->mc = *cfg;
+  c->iters_done = 0;
+  c->have_chains = true;
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(c->stream));  // q0/data may be host buffers the caller reuses
+  return RSF_OK;
+}
+
+int rsf_mcmc_get_state(rsf_ctx *c, double *q, double *ssq, double *std2, double *V) {
+  if (!c) return fail(RSF_ERR_INVALID, "rsf_mcmc_get_state: NULL ctx");
+  if (!c->have_chains) return fail(RSF_ERR_STATE, "rsf_mcmc_get_state: call rsf_mcmc_init first");
+  DeviceGuard guard(c->device);
+  const int d = c->mc.n_params;
+  const size_t cb = (size_t)c->mc.n_chains * sizeof(double);
+  const hipMemcpyKind kind = host_mem(c) ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
+  if (q) HIP_TRY(hipMemcpyAsync(q, c->q.p, cb * d, kind, c->stream));
+  if (ssq) HIP_TRY(hipMemcpyAsync(ssq, c->ssq.p, cb, kind, c->stream));
+  if (std2) HIP_TRY(hipMemcpyAsync(std2, c->std2.p, cb, kind, c->stream));
+  if (V) HIP_TRY(hipMemcpyAsync(V, c->V.p, cb * d * d, kind, c->stream));
+  return finish(c);
+}
+
+int rsf_mcmc_set_state(rsf_ctx *c, const double *q, const double *ssq, const double *std2, const double *V) {
+  if (!c) return fail(RSF_ERR_INVALID, "rsf_mcmc_set_state: NULL ctx");
+  if (!c->have_chains) return fail(RSF_ERR_STATE, "rsf_mcmc_set_state: call rsf_mcmc_init first");
+  DeviceGuard guard(c->device);
+  const int d = c->mc.n_params;
+  const size_t cb = (size_t)c->mc.n_chains * sizeof(double);
+  const hipMemcpyKind kind = host_mem(c) ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
+  if (q) HIP_TRY(hipMemcpyAsync(c->q.p, q, cb * d, kind, c->stream));
+  if (ssq) HIP_TRY(hipMemcpyAsync(c->ssq.p, ssq, cb, kind, c->stream));
+  if (std2) HIP_TRY(hipMemcpyAsync(c->std2.p, std2, cb, kind, c->stream));
+  if (V) HIP_TRY(hipMemcpyAsync(c->V.p, V, cb * d * d, kind, c->stream));
+  return finish(c);
+}
+
+int rsf_mcmc_run(rsf_ctx *c, int64_t n_iters, double *tq, double *ts, uint8_t *ta) {
+  return run_mcmc(c, n_iters, nullptr, nullptr, nullptr, tq, ts, ta, false);
+}
+
+int rsf_mcmc_replay(rsf_ctx *c, int64_t n_iters, const double *z, const double *u, const double *g,
+                    double *tq, double *ts, uint8_t *ta) {
+  if (!z || !u || !g) return fail(RSF_ERR_INVALID, "rsf_mcmc_replay: z, u and g are required");
+  return run_mcmc(c, n_iters, z, u, g, tq, ts, ta, true);
+}
+
+int rsf_mcmc_stats(rsf_ctx *c, int64_t *n_acc, int64_t *n_eval, int64_t *n_nonfinite, int64_t *n_done) {
+  if (!c) return fail(RSF_ERR_INVALID, "rsf_mcmc_stats: NULL ctx");
+  if (!c->have_chains) return fail(RSF_ERR_STATE, "rsf_mcmc_stats: call rsf_mcmc_init first");
+  DeviceGuard guard(c->device);
+  unsigned long long s[3];
+  HIP_TRY(hipMemcpyAsync(s, c->stats.p, sizeof s, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  if (n_acc) *n_acc = (int64_t)s[0];
+  if (n_eval) *n_eval = (int64_t)s[1];
+  if (n_nonfinite) *n_nonfinite = (int64_t)s[2];
+  if (n_done) *n_done = c->iters_done;
+  return RSF_OK;
+}
+
+int rsf_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
+  if (!ctr || !key || !out) return fail(RSF_ERR_INVALID, "rsf_philox4x32_10: NULL argument");
+  uint32_t *d = nullptr;
+  HIP_TRY(hipMalloc(&d, 4 * sizeof(uint32_t)));
+  hipLaunchKernelGGL(probe_philox_kernel, dim3(1), dim3(64), 0, nullptr, ctr[0], ctr[1], ctr[2], ctr[3], key[0], key[1], d);
+  hipError_t e = hipMemcpy(out, d, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost);
+  (void)hipFree(d);
+  if (e != hipSuccess) return fail(RSF_ERR_DEVICE, "rsf_philox4x32_10: %s", hipGetErrorString(e));
+  return RSF_OK;
+}
+
+int rsf_mcmc_draws(uint64_t seed, int64_t chain, int64_t iteration, int32_t d, double shape, double *z, double *u,
+                   double *g) {
+  if (d < 1 || d > 3) return fail(RSF_ERR_INVALID, "rsf_mcmc_draws: n_params out of range");
+  double *dev = nullptr, h[5];
+  HIP_TRY(hipMalloc(&dev, sizeof h));
+  hipLaunchKernelGGL(probe_draws_kernel, dim3(1), dim3(64), 0, nullptr, seed, (uint64_t)chain, (uint32_t)iteration, d, shape, dev);
+  hipError_t e = hipMemcpy(h, dev, sizeof h, hipMemcpyDeviceToHost);
+  (void)hipFree(dev);
+  if (e != hipSuccess) return fail(RSF_ERR_DEVICE, "rsf_mcmc_draws: %s", hipGetErrorString(e));
+  if (z) for (int p = 0; p < d; ++p) z[p] = h[p];
+  if (u) *u = h[3];
+  if (g) *g = h[4];
+  return RSF_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,89 @@
+"""
+Multi-GPU sharding of independent chains.
+
+Chains never exchange data while sampling, so the path shards with NO data-path collective:
+rank r owns the contiguous global chain ids [r*C/G, (r+1)*C/G) and runs them on its own GPU.
+The Philox counter is keyed by the GLOBAL chain id, hence the pooled result is bit-identical
+for any G.  The only collective is one all-gather of the post-burn-in sample block at the end
+(`torch.distributed.all_gather_into_tensor`: RCCL over xGMI with backend "nccl", gloo on CPU in
+the test-suite) — the "posterior pool".  One process per GPU; launch with torch.distributed.run.
+"""
+import os
+
+import numpy as np
+
+
+def shard_bounds(n_chains, world_size, rank):
+    """Contiguous block of global chain ids owned by `rank` (n_chains must divide evenly)."""
+    if n_chains % world_size:
+        raise ValueError(f"n_chains={n_chains} is not divisible by world_size={world_size}")
+    per = n_chains // world_size
+    return rank * per, per
+
+
+def init_process_group(backend=None):
+    """Join the job described by RANK / WORLD_SIZE / MASTER_* (torch.distributed.run sets them)."""
+    import torch
+    import torch.distributed as dist
+
+    if dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29500")
+    if backend is None:
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+    if backend == "nccl":
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", rank)))
+    dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world
+
+
+def allgather_pool(local, group=None):
+    """local: tensor (n_keep, C_local, d) on this rank → (G, n_keep, C_local, d) on every rank."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    local = local.contiguous()
+    out = torch.empty((world,) + tuple(local.shape), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(out, local, group=group)
+    return out
+
+
+def pool_to_chain_major(pool):
+    """(G, n_keep, C_local, d) → (n_keep, G*C_local, d): global chain id = g*C_local + c."""
+    G, n, C, d = pool.shape
+    return pool.permute(1, 0, 2, 3).reshape(n, G * C, d)
+
+
+def run_sharded(engine_factory, model, substeps, data, q0_global, lo, hi, n_iters, nburn, seed=0, mcmc_kwargs=None,
+                device=None):
+    """Each rank samples its shard, then the kept draws are all-gathered.
+
+    engine_factory() → Engine for this rank (the product passes `lambda: Engine(mem="device")`;
+    the CPU test-suite passes an oracle-backed factory).  q0_global: (C, d) start points for ALL
+    chains, identical on every rank.  Returns (pool (n_keep, C, d) torch tensor, local stats)."""
+    import torch
+    import torch.distributed as dist
+
+    rank, world = dist.get_rank(), dist.get_world_size()
+    q0_global = np.asarray(q0_global, dtype=np.float64)
+    q0_global = q0_global.reshape(q0_global.shape[0], -1)
+    off, per = shard_bounds(q0_global.shape[0], world, rank)
+    eng = engine_factory()
+    try:
+        eng.set_model(model, substeps)
+        eng.mcmc_init(q0_global[off:off + per], data, lo, hi, seed=seed, chain_offset=off, **(mcmc_kwargs or {}))
+        tq, _, _ = eng.mcmc_run(n_iters, traces=("q",))
+        eng.sync()
+        stats = eng.stats()
+        kept = tq[max(nburn - 1, 0):]
+        if not isinstance(kept, torch.Tensor):
+            kept = torch.from_numpy(np.ascontiguousarray(kept))
+        if device is not None:
+            kept = kept.to(device)
+        pool = pool_to_chain_major(allgather_pool(kept))
+    finally:
+        eng.close()
+    return pool, stats

@@ -1,0 +1,195 @@
+"""
+Engine — thin object wrapper over the C ABI (include/rsf_abi.h).
+
+One Engine owns one rsf_ctx.  With mem="host" every array argument is a NumPy array and calls
+are synchronous; with mem="device" arguments are torch CUDA tensors (PyTorch is used only for
+device memory and streams) and the work is ordered on the current torch stream.
+
+The class is library-agnostic (`lib` is any handle typed by _abi.bind) so the test-suite can
+drive the CPU oracle through the very same code; the product always passes _abi.load().
+"""
+import ctypes
+
+import numpy as np
+
+from . import _abi
+
+
+def _model_struct(model, substeps):
+    m = _abi.Model()
+    m.size = ctypes.sizeof(_abi.Model)
+    m.flags = _abi.FLAG_RADIATION_DAMPING if getattr(model, "RadiationDamping", True) else 0
+    m.nsteps = int(model.num_tsteps)
+    m.substeps = int(substeps)
+    m.t_start, m.t_final = float(model.t_start), float(model.t_final)
+    m.mu_ref, m.V_ref, m.k1 = float(model.mu_ref), float(model.V_ref), float(model.k1)
+    m.mu_t_zero = float(model.mu_t_zero)
+    m.a, m.b = float(model.a), float(model.b)
+    return m
+
+
+class Engine:
+    def __init__(self, lib=None, mem="host", device=-1, block_threads=0, cpu_threads=0, stream=None):
+        if lib is None:
+            lib = _abi.load()
+            _abi.require_device(lib)
+        self.lib = lib
+        self.mem = mem
+        self._torch = None
+        cfg = _abi.Config()
+        cfg.size, cfg.version = ctypes.sizeof(_abi.Config), _abi.ABI_VERSION
+        cfg.device = device
+        cfg.mem_space = _abi.MEM_DEVICE if mem == "device" else _abi.MEM_HOST
+        cfg.block_threads, cfg.cpu_threads = block_threads, cpu_threads
+        if mem == "device":
+            import torch
+
+            self._torch = torch
+            if device >= 0:
+                torch.cuda.set_device(device)
+            if stream is None:
+                stream = torch.cuda.current_stream().cuda_stream
+        cfg.stream = stream
+        self._ctx = ctypes.c_void_p()
+        _abi.check(lib, lib.rsf_create(ctypes.byref(cfg), ctypes.byref(self._ctx)))
+        self.nout = None
+        self.n_chains = self.n_params = None
+
+    # -- lifetime -------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_ctx", None):
+            self.lib.rsf_destroy(self._ctx)
+            self._ctx = None
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def sync(self):
+        _abi.check(self.lib, self.lib.rsf_sync(self._ctx))
+
+    # -- buffers --------------------------------------------------------------------------
+    def _empty(self, shape, dtype=np.float64):
+        if self.mem == "device":
+            t = self._torch
+            return t.empty(shape, dtype=t.uint8 if dtype == np.uint8 else t.float64, device="cuda")
+        return np.empty(shape, dtype=dtype)
+
+    def _in(self, x, dtype=np.float64):
+        """Contiguous array in this engine's memory space (None passes through)."""
+        if x is None:
+            return None
+        if self.mem == "device":
+            t = self._torch
+            if not isinstance(x, t.Tensor):
+                x = t.as_tensor(np.ascontiguousarray(x, dtype=dtype))
+            return x.to(device="cuda", dtype=t.float64).contiguous()
+        return np.ascontiguousarray(x, dtype=dtype)
+
+    @staticmethod
+    def _ptr(x):
+        if x is None:
+            return None
+        if isinstance(x, np.ndarray):
+            return x.ctypes.data
+        return x.data_ptr()
+
+    # -- forward model --------------------------------------------------------------------
+    def set_model(self, model, substeps=1):
+        m = _model_struct(model, substeps)
+        _abi.check(self.lib, self.lib.rsf_set_model(self._ctx, ctypes.byref(m)))
+        n = ctypes.c_int32()
+        _abi.check(self.lib, self.lib.rsf_model_nout(self._ctx, ctypes.byref(n)))
+        self.nout = n.value
+        return self.nout
+
+    def forward(self, dc, a=None, b=None, data=None, want_ssq=False, want_acc=True):
+        """→ (ssq[C] | None, acc[nout, C] | None) for C parameter sets."""
+        dc = self._in(np.atleast_1d(dc) if not hasattr(dc, "data_ptr") else dc)
+        C = int(dc.shape[0])
+        a, b, data = self._in(a), self._in(b), self._in(data)
+        if want_ssq and data is None:
+            raise ValueError("want_ssq needs data")
+        if data is not None and int(data.shape[0]) != self.nout:
+            raise ValueError(f"data has {int(data.shape[0])} entries, the model produces {self.nout}")
+        ssq = self._empty((C,)) if want_ssq else None
+        acc = self._empty((self.nout, C)) if want_acc else None
+        _abi.check(self.lib, self.lib.rsf_forward_batch(self._ctx, C, self._ptr(dc), self._ptr(a), self._ptr(b),
+                                                        self._ptr(data), self._ptr(ssq), self._ptr(acc)))
+        return ssq, acc
+
+    # -- sampler --------------------------------------------------------------------------
+    def mcmc_init(self, q0, data, lo, hi, seed=0, chain_offset=0, n0=0.01, prior_len=0, adapt_mode="none",
+                  adapt_interval=10, fd_rel_step=1e-6):
+        q0 = self._in(q0)
+        if q0.ndim == 1:
+            q0 = q0.reshape(-1, 1)
+        C, d = int(q0.shape[0]), int(q0.shape[1])
+        data = self._in(data)
+        if int(data.shape[0]) != self.nout:
+            raise ValueError(f"data has {int(data.shape[0])} entries, the model produces {self.nout}")
+        lo, hi = np.broadcast_to(np.asarray(lo, dtype=np.float64), (d,)), np.broadcast_to(np.asarray(hi, dtype=np.float64), (d,))
+        cfg = _abi.McmcConfig()
+        cfg.size = ctypes.sizeof(_abi.McmcConfig)
+        cfg.n_params, cfg.n_chains, cfg.chain_offset = d, C, int(chain_offset)
+        cfg.seed, cfg.n0, cfg.prior_len = int(seed), float(n0), int(prior_len)
+        cfg.adapt_mode = _abi.ADAPT_MODES[adapt_mode] if isinstance(adapt_mode, str) else int(adapt_mode)
+        cfg.adapt_interval, cfg.fd_rel_step = int(adapt_interval), float(fd_rel_step)
+        for p in range(d):
+            cfg.lo[p], cfg.hi[p] = float(lo[p]), float(hi[p])
+        _abi.check(self.lib, self.lib.rsf_mcmc_init(self._ctx, ctypes.byref(cfg), self._ptr(q0), self._ptr(data)))
+        self.n_chains, self.n_params = C, d
+
+    def get_state(self):
+        C, d = self.n_chains, self.n_params
+        q, ssq, std2, V = self._empty((C, d)), self._empty((C,)), self._empty((C,)), self._empty((C, d, d))
+        _abi.check(self.lib, self.lib.rsf_mcmc_get_state(self._ctx, self._ptr(q), self._ptr(ssq), self._ptr(std2), self._ptr(V)))
+        return q, ssq, std2, V
+
+    def set_state(self, q=None, ssq=None, std2=None, V=None):
+        q, ssq, std2, V = self._in(q), self._in(ssq), self._in(std2), self._in(V)
+        _abi.check(self.lib, self.lib.rsf_mcmc_set_state(self._ctx, self._ptr(q), self._ptr(ssq), self._ptr(std2), self._ptr(V)))
+
+    def _traces(self, n_iters, want):
+        C, d = self.n_chains, self.n_params
+        if want is True:
+            want = ("q", "std2", "accept")
+        want = want or ()
+        tq = self._empty((n_iters, C, d)) if "q" in want else None
+        ts = self._empty((n_iters, C)) if "std2" in want else None
+        ta = self._empty((n_iters, C), np.uint8) if "accept" in want else None
+        return tq, ts, ta
+
+    def mcmc_run(self, n_iters, traces=True, out=None):
+        """n_iters fused iterations for every chain → (trace_q[n,C,d], trace_std2[n,C], accept[n,C])."""
+        tq, ts, ta = out if out is not None else self._traces(n_iters, traces)
+        _abi.check(self.lib, self.lib.rsf_mcmc_run(self._ctx, int(n_iters), self._ptr(tq), self._ptr(ts), self._ptr(ta)))
+        return tq, ts, ta
+
+    def mcmc_replay(self, z, u, g, traces=True):
+        z, u, g = self._in(z), self._in(u), self._in(g)
+        n_iters = int(u.shape[0])
+        tq, ts, ta = self._traces(n_iters, traces)
+        _abi.check(self.lib, self.lib.rsf_mcmc_replay(self._ctx, n_iters, self._ptr(z), self._ptr(u), self._ptr(g),
+                                                      self._ptr(tq), self._ptr(ts), self._ptr(ta)))
+        return tq, ts, ta
+
+    def stats(self):
+        v = [ctypes.c_int64() for _ in range(4)]
+        _abi.check(self.lib, self.lib.rsf_mcmc_stats(self._ctx, *[ctypes.byref(x) for x in v]))
+        return dict(zip(("accepted", "evaluated", "nonfinite", "iters_done"), (x.value for x in v)))
+
+    # -- RNG helpers (tests) --------------------------------------------------------------
+    def philox(self, ctr, key):
+        c, k, o = (ctypes.c_uint32 * 4)(*ctr), (ctypes.c_uint32 * 2)(*key), (ctypes.c_uint32 * 4)()
+        _abi.check(self.lib, self.lib.rsf_philox4x32_10(c, k, o))
+        return list(o)
+
+    def draws(self, seed, chain, iteration, n_params, shape):
+        z, u, g = (ctypes.c_double * 3)(), ctypes.c_double(), ctypes.c_double()
+        _abi.check(self.lib, self.lib.rsf_mcmc_draws(seed, chain, iteration, n_params, shape, z, ctypes.byref(u), ctypes.byref(g)))
+        return list(z)[:n_params], u.value, g.value

@@ -1,0 +1,192 @@
+/*
+ * rsf_abi.h — C ABI of the MCMC-over-ODE hot path (rate-and-state friction).
+ *
+ * This is the drop-in boundary.  The reference (pure Python, no FFI) exposes the
+ * path only through three classes; each entry point below names the reference
+ * code it stands in for (paths relative to the reference tree):
+ *
+ *   RateStateModel.__init__/.evaluate   RateStateModel.py:109-186, 188-395
+ *   RHS friction(t, y)                  RateStateModel.py:277-355
+ *   MCMC.compute_initial_covariance     MCMC.py:206-266
+ *   MCMC.SSqcalc / acceptreject         MCMC.py:335-389, 268-333
+ *   MCMC.update_standard_deviation      MCMC.py:129-160
+ *   MCMC.update_covariance_matrix       MCMC.py:162-204
+ *   MCMC.sample (hot loop)              MCMC.py:391-544
+ *
+ * Two shared libraries implement this same header:
+ *   - librsf_hip.so     (the product: hand-written gfx950 HIP kernels)
+ *   - librsf_oracle.so  (oracle/: plain-C CPU restatement; TEST INFRASTRUCTURE ONLY)
+ *
+ * Conventions
+ *   - plain C symbols, no C++ types, no exceptions across the boundary;
+ *   - every function returns int status (RSF_OK == 0, negative == error);
+ *     rsf_last_error() returns a thread-local message for the last failure;
+ *   - all array arguments are caller-allocated and caller-owned; ctx->mem_space
+ *     says whether they are host pointers (the shim stages them) or device
+ *     pointers (e.g. torch.Tensor.data_ptr(), hipMalloc) used in place;
+ *   - all floating point is IEEE float64;
+ *   - a ctx is single-owner: one host thread at a time; distinct ctxs are
+ *     independent; work is launched on the ctx stream and every call that
+ *     returns results to HOST memory is synchronous on return; with DEVICE
+ *     memory calls are stream-ordered and rsf_sync() waits for them.
+ *
+ * Parameter vector of a chain: q[0] = Dc (the reference's only parameter,
+ * MCMC.py:381); for d == 3 (extension, BASELINE config 5) q = (Dc, a, b).
+ */
+#ifndef RSF_ABI_H
+#define RSF_ABI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RSF_ABI_VERSION 1
+
+/* status codes */
+#define RSF_OK 0
+#define RSF_ERR_INVALID (-1)     /* bad argument */
+#define RSF_ERR_DEVICE (-2)      /* HIP runtime failure / no device */
+#define RSF_ERR_STATE (-3)       /* call order (model or chains not initialised) */
+#define RSF_ERR_NOMEM (-4)
+#define RSF_ERR_UNSUPPORTED (-5)
+
+/* where caller buffers live */
+#define RSF_MEM_HOST 0
+#define RSF_MEM_DEVICE 1
+
+/* rsf_model.flags */
+#define RSF_FLAG_RADIATION_DAMPING 1u /* RateStateModel.RadiationDamping, RateStateModel.py:183 */
+
+/* rsf_mcmc_config.adapt_mode (MCMC.py:162-204, 523-527) */
+#define RSF_ADAPT_NONE 0           /* list prior: adaptation raises and is swallowed => never adapts */
+#define RSF_ADAPT_REFERENCE_DICT 1 /* dict prior: V <- chol(2.38^2/2 * cov(window)), then used AS covariance */
+#define RSF_ADAPT_AM 2             /* corrected adaptive Metropolis: V <- 2.38^2/d * cov(window) */
+
+#define RSF_MAX_PARAMS 3
+
+typedef struct rsf_ctx rsf_ctx;
+
+typedef struct rsf_config {
+  uint32_t size;          /* = sizeof(rsf_config) */
+  uint32_t version;       /* = RSF_ABI_VERSION */
+  int32_t device;         /* HIP device ordinal; -1 = current device */
+  int32_t mem_space;      /* RSF_MEM_HOST or RSF_MEM_DEVICE for every array argument */
+  void *stream;           /* hipStream_t to launch on; NULL = a ctx-owned stream */
+  uint32_t block_threads; /* workgroup size (multiple of 64); 0 = default */
+  uint32_t cpu_threads;   /* oracle library only: OpenMP threads, 0 = all */
+} rsf_config;
+
+/* Mirrors the attributes of RateStateModel (RateStateModel.py:167-184). */
+typedef struct rsf_model {
+  uint32_t size;    /* = sizeof(rsf_model) */
+  uint32_t flags;   /* RSF_FLAG_* */
+  int32_t nsteps;   /* num_tsteps (number_time_steps) */
+  int32_t substeps; /* RK4 steps per output interval delta_t (>= 1) */
+  double t_start;
+  double t_final;
+  double mu_ref;
+  double V_ref;
+  double k1;
+  double mu_t_zero;
+  double a; /* used where no per-chain a is given */
+  double b; /* used where no per-chain b is given */
+} rsf_model;
+
+typedef struct rsf_mcmc_config {
+  uint32_t size;          /* = sizeof(rsf_mcmc_config) */
+  int32_t n_params;       /* d: 1 (Dc) or 3 (Dc, a, b) */
+  int64_t n_chains;       /* C: chains owned by this ctx */
+  int64_t chain_offset;   /* global id of local chain 0 (multi-GPU sharding; keys the RNG) */
+  uint64_t seed;          /* Philox4x32-10 key */
+  double n0;              /* MCMC.n0 = 0.01, MCMC.py:97 */
+  int32_t prior_len;      /* len(qpriors) quirk in std2[0] divisor, MCMC.py:261: 3 list / 2 dict; 0 => d */
+  int32_t adapt_mode;     /* RSF_ADAPT_* */
+  int32_t adapt_interval; /* MCMC.adapt_interval, default 10 */
+  int32_t reserved;
+  double fd_rel_step;     /* 1e-6, MCMC.py:251 */
+  double lo[RSF_MAX_PARAMS]; /* strict box prior, MCMC.py:318-320 */
+  double hi[RSF_MAX_PARAMS];
+} rsf_mcmc_config;
+
+/* ---- library level ---------------------------------------------------------------- */
+int rsf_version(void);
+const char *rsf_backend(void);    /* "hip-gfx950" | "oracle-cpu" */
+const char *rsf_last_error(void); /* thread-local, never NULL */
+int rsf_device_count(void);       /* >= 0, or negative status */
+
+int rsf_create(const rsf_config *cfg, rsf_ctx **out);
+int rsf_destroy(rsf_ctx *ctx);
+int rsf_sync(rsf_ctx *ctx);
+
+/* ---- forward model: RateStateModel (RateStateModel.py:109-395) -------------------- */
+
+/* Stores the model attributes and builds the chain-independent loading table
+ * V_l(t) = V_ref (1 + exp(-t/20) sin(10 t)) (RateStateModel.py:327-329) at the
+ * 2*substeps*(nout-1)+1 RK4 stage times. */
+int rsf_set_model(rsf_ctx *ctx, const rsf_model *model);
+
+/* Length of the output series: int(floor((t_final-t_start)/delta_t)), RateStateModel.py:358. */
+int rsf_model_nout(rsf_ctx *ctx, int32_t *nout);
+
+/* Batched RateStateModel.evaluate()[1] (+ MCMC.SSqcalc, MCMC.py:381-387) for C
+ * independent parameter sets.
+ *   dc[C]              Dc per lane
+ *   a[C], b[C]         optional (NULL => model.a / model.b)
+ *   data[nout]         optional observation; needed iff ssq_out != NULL
+ *   ssq_out[C]         optional: sum_k (acc_k - data_k)^2, k = 0..nout-1 (acc_0 = 0)
+ *   acc_out[nout][C]   optional: clean acceleration series, TIME-MAJOR (row k = time k) */
+int rsf_forward_batch(rsf_ctx *ctx, int64_t n_lanes, const double *dc, const double *a,
+                      const double *b, const double *data, double *ssq_out, double *acc_out);
+
+/* ---- sampler: MCMC (MCMC.py:4-544) ------------------------------------------------- */
+
+/* MCMC.__init__ + compute_initial_covariance + the initial SSqcalc (MCMC.py:464-468),
+ * per chain: std2_0 = SSq(q0)/(nout - prior_len); Vstart = std2_0 * (X^T X)^-1 with X the
+ * forward-difference sensitivity (perturbed-Dc denominator quirk kept, MCMC.py:251,264).
+ * For d == 3 the sensitivity is taken per parameter (extension).
+ *   q0[C][d]     start point per chain
+ *   data[nout]   observation shared by all chains of this ctx (kept by the ctx) */
+int rsf_mcmc_init(rsf_ctx *ctx, const rsf_mcmc_config *cfg, const double *q0, const double *data);
+
+/* Read / overwrite the per-chain sampler state.  Any pointer may be NULL.
+ *   q[C][d], ssq[C], std2[C], V[C][d][d] (proposal covariance "Vold", row-major) */
+int rsf_mcmc_get_state(rsf_ctx *ctx, double *q, double *ssq, double *std2, double *V);
+int rsf_mcmc_set_state(rsf_ctx *ctx, const double *q, const double *ssq, const double *std2,
+                       const double *V);
+
+/* n_iters iterations of the hot loop (MCMC.py:494-527) for every chain, fused in one
+ * launch.  Draws come from Philox4x32-10 keyed by (seed; global chain id, iteration, slot).
+ *   trace_q[n_iters][C][d]   optional: state after each iteration (qparams columns 1..)
+ *   trace_std2[n_iters][C]   optional: sigma^2 after each iteration (std2[1:])
+ *   trace_accept[n_iters][C] optional: 1 = accepted */
+int rsf_mcmc_run(rsf_ctx *ctx, int64_t n_iters, double *trace_q, double *trace_std2,
+                 uint8_t *trace_accept);
+
+/* Same iteration logic, consuming caller-supplied variates instead of Philox:
+ *   z[n_iters][C][d] standard normals (proposal = q + chol(V) z; d == 1: q + sqrt(V) z)
+ *   u[n_iters][C]    uniforms for the accept test (read only when the proposal is in bounds)
+ *   g[n_iters][C]    standard Gamma(0.5 (n0 + nout)) variates for the sigma^2 update */
+int rsf_mcmc_replay(rsf_ctx *ctx, int64_t n_iters, const double *z, const double *u,
+                    const double *g, double *trace_q, double *trace_std2, uint8_t *trace_accept);
+
+/* Totals since rsf_mcmc_init over this ctx's chains: accepted proposals, proposals that
+ * were in bounds (= forward solves), in-bounds proposals whose SSq was NaN/Inf, iterations
+ * done per chain.  Any pointer may be NULL. */
+int rsf_mcmc_stats(rsf_ctx *ctx, int64_t *n_accepted, int64_t *n_evaluated, int64_t *n_nonfinite,
+                   int64_t *n_iters_done);
+
+/* The Philox4x32-10 block function itself (known-answer tests; Random123 vectors). */
+int rsf_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
+
+/* The variates rsf_mcmc_run would draw for (seed, global chain id, iteration): d proposal
+ * normals, the accept uniform and the Gamma(shape) variate.  Host-side, for tests. */
+int rsf_mcmc_draws(uint64_t seed, int64_t chain, int64_t iteration, int32_t n_params, double shape,
+                   double *z, double *u, double *g);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RSF_ABI_H */

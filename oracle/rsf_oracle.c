@@ -1,0 +1,549 @@
+/*
+ * rsf_oracle.c — CPU restatement of the MCMC-over-ODE hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing in the product path may load this library;
+ * only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg do, and only as the
+ * checker / timed baseline.  It implements include/rsf_abi.h on the host (RSF_MEM_HOST only).
+ *
+ * What it restates (paths relative to the reference tree):
+ *   friction()        RateStateModel.py:318-355   literal operation order, no FMA contraction
+ *   evaluate()        RateStateModel.py:358-395   with the reference's adaptive dop853 replaced
+ *                                                 by the fixed-step RK4 that BASELINE.json names
+ *   SSqcalc           MCMC.py:381-387
+ *   acceptreject      MCMC.py:318-333
+ *   sigma^2 update    MCMC.py:158-160
+ *   initial cov.      MCMC.py:244-266
+ *   adaptation        MCMC.py:200-204, 523-527
+ *   sample() loop     MCMC.py:494-527
+ *
+ * Parity pinning: the reference ships no tests or golden vectors.  This restatement is pinned
+ * by tests/golden/ (captured from the live reference import by oracle/make_golden.py):
+ *   - tier 2: RK4(substeps S) converges to the reference's dop853 trajectory at 16x per
+ *     halving (tests/test_oracle_golden.py);
+ *   - sampler logic: the Python twin oracle/rsf_oracle.py replays the reference's recorded
+ *     draws exactly; this C file is checked against that twin.
+ * The RNG (Philox4x32-10 + Box-Muller + Marsaglia-Tsang) has no reference counterpart (the
+ * reference uses NumPy's global MT19937 stream); Philox is pinned by Random123's known-answer
+ * vectors.
+ */
+#include "../include/rsf_abi.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+static __thread char g_err[512] = "";
+
+static int fail(int code, const char *msg) {
+  snprintf(g_err, sizeof g_err, "%s", msg);
+  return code;
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* Philox4x32-10 (Salmon et al., SC'11; Random123 constants)                             */
+/* ------------------------------------------------------------------------------------ */
+static void philox_block(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
+  uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3];
+  uint32_t k0 = key[0], k1 = key[1];
+  for (int r = 0; r < 10; ++r) {
+    uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+    uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+    uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+    uint32_t n1 = (uint32_t)p1;
+    uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    uint32_t n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+/* Draw slots of one (chain, iteration):
+ *   slot 0: proposal normals z0, z1     slot 1: proposal normal z2
+ *   slot 2: accept uniform              slot 8+2j / 9+2j: gamma attempt j (normal / uniform) */
+enum { SLOT_Z01 = 0, SLOT_Z2 = 1, SLOT_U = 2, SLOT_GAMMA = 8 };
+
+static void draw_words(uint64_t seed, uint64_t chain, uint32_t iter, uint32_t slot, uint32_t w[4]) {
+  uint32_t ctr[4] = {(uint32_t)chain, (uint32_t)(chain >> 32), iter, slot};
+  uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+  philox_block(ctr, key, w);
+}
+
+/* 53-bit uniform in (0, 1] */
+static double u53(uint32_t hi, uint32_t lo) {
+  uint64_t k = (((uint64_t)hi << 32) | lo) >> 11;
+  return (double)(k + 1) * 0x1.0p-53;
+}
+
+static void normal_pair(const uint32_t w[4], double *z0, double *z1) {
+  double u1 = u53(w[0], w[1]), u2 = u53(w[2], w[3]);
+  double r = sqrt(-2.0 * log(u1));
+  double th = 6.283185307179586476925286766559 * u2;
+  *z0 = r * cos(th);
+  *z1 = r * sin(th);
+}
+
+/* Marsaglia & Tsang (2000), shape >= 1, log acceptance test only (no squeeze). */
+static double gamma_draw(uint64_t seed, uint64_t chain, uint32_t iter, double shape) {
+  double d = shape - 1.0 / 3.0;
+  double c = 1.0 / sqrt(9.0 * d);
+  for (uint32_t j = 0; j < 64; ++j) {
+    uint32_t w[4];
+    double x, unused, u, v;
+    draw_words(seed, chain, iter, SLOT_GAMMA + 2 * j, w);
+    normal_pair(w, &x, &unused);
+    v = 1.0 + c * x;
+    if (!(v > 0.0)) continue;
+    v = v * v * v;
+    draw_words(seed, chain, iter, SLOT_GAMMA + 2 * j + 1, w);
+    u = u53(w[0], w[1]);
+    if (log(u) < 0.5 * x * x + d * (1.0 - v + log(v))) return d * v;
+  }
+  return d; /* unreachable in practice (acceptance > 0.95 per attempt) */
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* context                                                                                */
+/* ------------------------------------------------------------------------------------ */
+struct rsf_ctx {
+  rsf_config cfg;
+  int have_model;
+  rsf_model m;
+  int32_t nout;
+  double delta_t, h;
+  /* sampler */
+  int have_chains;
+  rsf_mcmc_config mc;
+  double *data;                 /* [nout] */
+  double *q, *ssq, *std2, *V;   /* [C][d], [C], [C], [C][d][d] */
+  double *wref, *wsum, *wsq;    /* adaptation window: shift [C][d], sums [C][d], [C][d][d] */
+  int32_t *wn;                  /* [C] samples in window */
+  int64_t iters_done;
+  int64_t n_acc, n_eval, n_nonfinite;
+};
+
+int rsf_version(void) { return RSF_ABI_VERSION; }
+const char *rsf_backend(void) { return "oracle-cpu"; }
+const char *rsf_last_error(void) { return g_err; }
+int rsf_device_count(void) { return 0; }
+
+int rsf_create(const rsf_config *cfg, rsf_ctx **out) {
+  if (!cfg || !out) return fail(RSF_ERR_INVALID, "rsf_create: NULL argument");
+  if (cfg->size != sizeof(rsf_config) || cfg->version != RSF_ABI_VERSION)
+    return fail(RSF_ERR_INVALID, "rsf_create: config size/version mismatch");
+  if (cfg->mem_space != RSF_MEM_HOST)
+    return fail(RSF_ERR_UNSUPPORTED, "rsf_create: the CPU oracle takes host buffers only");
+  rsf_ctx *c = (rsf_ctx *)calloc(1, sizeof *c);
+  if (!c) return fail(RSF_ERR_NOMEM, "rsf_create: out of memory");
+  c->cfg = *cfg;
+  *out = c;
+  return RSF_OK;
+}
+
+static void free_chains(rsf_ctx *c) {
+  free(c->data); free(c->q); free(c->ssq); free(c->std2); free(c->V);
+  free(c->wref); free(c->wsum); free(c->wsq); free(c->wn);
+  c->data = c->q = c->ssq = c->std2 = c->V = c->wref = c->wsum = c->wsq = NULL;
+  c->wn = NULL;
+  c->have_chains = 0;
+}
+
+int rsf_destroy(rsf_ctx *c) {
+  if (!c) return RSF_OK;
+  free_chains(c);
+  free(c);
+  return RSF_OK;
+}
+
+int rsf_sync(rsf_ctx *c) { return c ? RSF_OK : fail(RSF_ERR_INVALID, "rsf_sync: NULL ctx"); }
+
+static int nthreads(const rsf_ctx *c) {
+#ifdef _OPENMP
+  return c->cfg.cpu_threads ? (int)c->cfg.cpu_threads : omp_get_max_threads();
+#else
+  (void)c;
+  return 1;
+#endif
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* forward model                                                                          */
+/* ------------------------------------------------------------------------------------ */
+int rsf_set_model(rsf_ctx *c, const rsf_model *m) {
+  if (!c || !m) return fail(RSF_ERR_INVALID, "rsf_set_model: NULL argument");
+  if (m->size != sizeof(rsf_model)) return fail(RSF_ERR_INVALID, "rsf_set_model: struct size mismatch");
+  if (m->nsteps < 2 || m->substeps < 1 || !(m->t_final > m->t_start))
+    return fail(RSF_ERR_INVALID, "rsf_set_model: need nsteps >= 2, substeps >= 1, t_final > t_start");
+  c->m = *m;
+  c->delta_t = (m->t_final - m->t_start) / m->nsteps;                   /* RateStateModel.py:176 */
+  c->nout = (int32_t)floor((m->t_final - m->t_start) / c->delta_t);     /* RateStateModel.py:358 */
+  c->h = c->delta_t / m->substeps;
+  c->have_model = 1;
+  return RSF_OK;
+}
+
+int rsf_model_nout(rsf_ctx *c, int32_t *nout) {
+  if (!c || !nout) return fail(RSF_ERR_INVALID, "rsf_model_nout: NULL argument");
+  if (!c->have_model) return fail(RSF_ERR_STATE, "rsf_model_nout: call rsf_set_model first");
+  *nout = c->nout;
+  return RSF_OK;
+}
+
+/* RateStateModel.py:318-355, literal operation order. */
+static void friction(const rsf_model *m, double t, double dc, double a, double b, const double y[3],
+                     double dydt[3]) {
+  double V_ref = m->V_ref;
+  double kprime = 1e-2 * 10 / dc;
+  double a1 = 20, a2 = 10;
+  double V_l = V_ref * (1 + exp(-t / a1) * sin(a2 * t));
+  double temp = 1 / a * (y[0] - m->mu_ref - b * log(V_ref * y[1] / dc));
+  double v = V_ref * exp(temp);
+  dydt[1] = 1. - v * y[1] / dc;
+  dydt[0] = kprime * V_l - kprime * v;
+  dydt[2] = v / a * (dydt[0] - b / y[1] * dydt[1]);
+  if (m->flags & RSF_FLAG_RADIATION_DAMPING) {
+    dydt[0] = dydt[0] - m->k1 * dydt[2];
+    dydt[2] = v / a * (dydt[0] - b / y[1] * dydt[1]);
+  }
+}
+
+/* One forward solve: fixed-step classical RK4, `substeps` steps per output interval.
+ * Stage times are t_start + j*(h/2) with integer j, so that the product's tabulated V_l
+ * sees bit-identical arguments.  Returns SSq if data != NULL; writes acc[k*stride] if acc. */
+static double solve(const rsf_ctx *c, double dc, double a, double b, const double *data, double *acc,
+                    int64_t stride) {
+  const rsf_model *m = &c->m;
+  const int S = m->substeps;
+  const double h = c->h, hh = 0.5 * c->h;
+  double y[3] = {m->mu_t_zero, dc / m->V_ref, m->V_ref}; /* RateStateModel.py:367-377 */
+  double vprev = m->V_ref;
+  double ssq = 0.0;
+  int64_t j = 0; /* half-step index of the current step start */
+  if (acc) acc[0] = 0.0;
+  if (data) ssq = (0.0 - data[0]) * (0.0 - data[0]);
+  for (int32_t k = 1; k < c->nout; ++k) {
+    for (int s = 0; s < S; ++s, j += 2) {
+      double k1[3], k2[3], k3[3], k4[3], ys[3];
+      double t0 = m->t_start + (double)j * hh;
+      double tm = m->t_start + (double)(j + 1) * hh;
+      double t1 = m->t_start + (double)(j + 2) * hh;
+      friction(m, t0, dc, a, b, y, k1);
+      for (int i = 0; i < 3; ++i) ys[i] = y[i] + hh * k1[i];
+      friction(m, tm, dc, a, b, ys, k2);
+      for (int i = 0; i < 3; ++i) ys[i] = y[i] + hh * k2[i];
+      friction(m, tm, dc, a, b, ys, k3);
+      for (int i = 0; i < 3; ++i) ys[i] = y[i] + h * k3[i];
+      friction(m, t1, dc, a, b, ys, k4);
+      for (int i = 0; i < 3; ++i) y[i] = y[i] + h / 6.0 * (k1[i] + 2.0 * k2[i] + 2.0 * k3[i] + k4[i]);
+    }
+    double ak = (y[2] - vprev) / c->delta_t; /* RateStateModel.py:388 */
+    vprev = y[2];
+    if (acc) acc[k * stride] = ak;
+    if (data) ssq += (ak - data[k]) * (ak - data[k]);
+  }
+  return ssq;
+}
+
+int rsf_forward_batch(rsf_ctx *c, int64_t n, const double *dc, const double *a, const double *b,
+                      const double *data, double *ssq_out, double *acc_out) {
+  if (!c || !dc || n < 0) return fail(RSF_ERR_INVALID, "rsf_forward_batch: bad argument");
+  if (!c->have_model) return fail(RSF_ERR_STATE, "rsf_forward_batch: call rsf_set_model first");
+  if (ssq_out && !data) return fail(RSF_ERR_INVALID, "rsf_forward_batch: ssq_out needs data");
+  int nt = nthreads(c);
+  (void)nt;
+#pragma omp parallel for schedule(static) num_threads(nt)
+  for (int64_t i = 0; i < n; ++i) {
+    double ai = a ? a[i] : c->m.a, bi = b ? b[i] : c->m.b;
+    double s = solve(c, dc[i], ai, bi, ssq_out ? data : NULL, acc_out ? acc_out + i : NULL, n);
+    if (ssq_out) ssq_out[i] = s;
+  }
+  return RSF_OK;
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* sampler                                                                                */
+/* ------------------------------------------------------------------------------------ */
+static double ssq_of(const rsf_ctx *c, const double *q, int d) {
+  double a = d == 3 ? q[1] : c->m.a, b = d == 3 ? q[2] : c->m.b;
+  return solve(c, q[0], a, b, c->data, NULL, 0);
+}
+
+/* lower Cholesky factor of a d x d covariance; a failed pivot zeroes that column. */
+static int chol_lower(const double *V, int d, double *L) {
+  int ok = 1;
+  memset(L, 0, sizeof(double) * d * d);
+  for (int j = 0; j < d; ++j) {
+    double s = V[j * d + j];
+    for (int k = 0; k < j; ++k) s -= L[j * d + k] * L[j * d + k];
+    if (!(s > 0.0)) { ok = 0; continue; }
+    double ljj = sqrt(s);
+    L[j * d + j] = ljj;
+    for (int i = j + 1; i < d; ++i) {
+      double t = V[i * d + j];
+      for (int k = 0; k < j; ++k) t -= L[i * d + k] * L[j * d + k];
+      L[i * d + j] = t / ljj;
+    }
+  }
+  return ok;
+}
+
+/* inverse of a symmetric 3x3 (adjugate / determinant) or 1x1 */
+static void sym_inverse(const double *A, int d, double *Ai) {
+  if (d == 1) { Ai[0] = 1.0 / A[0]; return; }
+  double c00 = A[4] * A[8] - A[5] * A[7], c01 = A[5] * A[6] - A[3] * A[8], c02 = A[3] * A[7] - A[4] * A[6];
+  double det = A[0] * c00 + A[1] * c01 + A[2] * c02;
+  double id = 1.0 / det;
+  Ai[0] = c00 * id; Ai[1] = (A[2] * A[7] - A[1] * A[8]) * id; Ai[2] = (A[1] * A[5] - A[2] * A[4]) * id;
+  Ai[3] = c01 * id; Ai[4] = (A[0] * A[8] - A[2] * A[6]) * id; Ai[5] = (A[2] * A[3] - A[0] * A[5]) * id;
+  Ai[6] = c02 * id; Ai[7] = (A[1] * A[6] - A[0] * A[7]) * id; Ai[8] = (A[0] * A[4] - A[1] * A[3]) * id;
+}
+
+int rsf_mcmc_init(rsf_ctx *c, const rsf_mcmc_config *cfg, const double *q0, const double *data) {
+  if (!c || !cfg || !q0 || !data) return fail(RSF_ERR_INVALID, "rsf_mcmc_init: NULL argument");
+  if (!c->have_model) return fail(RSF_ERR_STATE, "rsf_mcmc_init: call rsf_set_model first");
+  if (cfg->size != sizeof(rsf_mcmc_config)) return fail(RSF_ERR_INVALID, "rsf_mcmc_init: struct size mismatch");
+  if (cfg->n_params != 1 && cfg->n_params != 3) return fail(RSF_ERR_UNSUPPORTED, "rsf_mcmc_init: n_params must be 1 or 3");
+  if (cfg->n_chains < 1) return fail(RSF_ERR_INVALID, "rsf_mcmc_init: n_chains < 1");
+  if (cfg->adapt_mode == RSF_ADAPT_REFERENCE_DICT && cfg->n_params != 1)
+    return fail(RSF_ERR_UNSUPPORTED, "rsf_mcmc_init: reference_dict adaptation is defined for 1 parameter only");
+  if (cfg->adapt_mode < 0 || cfg->adapt_mode > RSF_ADAPT_AM || (cfg->adapt_mode && cfg->adapt_interval < 2))
+    return fail(RSF_ERR_INVALID, "rsf_mcmc_init: bad adapt_mode / adapt_interval");
+  free_chains(c);
+  c->mc = *cfg;
+  const int d = cfg->n_params;
+  const int64_t C = cfg->n_chains;
+  const int32_t N = c->nout;
+  c->data = (double *)malloc(sizeof(double) * N);
+  c->q = (double *)malloc(sizeof(double) * C * d);
+  c->ssq = (double *)malloc(sizeof(double) * C);
+  c->std2 = (double *)malloc(sizeof(double) * C);
+  c->V = (double *)malloc(sizeof(double) * C * d * d);
+  c->wref = (double *)malloc(sizeof(double) * C * d);
+  c->wsum = (double *)calloc(C * d, sizeof(double));
+  c->wsq = (double *)calloc(C * d * d, sizeof(double));
+  c->wn = (int32_t *)calloc(C, sizeof(int32_t));
+  if (!c->data || !c->q || !c->ssq || !c->std2 || !c->V || !c->wref || !c->wsum || !c->wsq || !c->wn) {
+    free_chains(c);
+    return fail(RSF_ERR_NOMEM, "rsf_mcmc_init: out of memory");
+  }
+  memcpy(c->data, data, sizeof(double) * N);
+  memcpy(c->q, q0, sizeof(double) * C * d);
+  memcpy(c->wref, q0, sizeof(double) * C * d);
+  const int plen = cfg->prior_len ? cfg->prior_len : d;
+  const double fd = cfg->fd_rel_step;
+  int nt = nthreads(c);
+  (void)nt;
+#pragma omp parallel num_threads(nt)
+  {
+    double *acc0 = (double *)malloc(sizeof(double) * N);
+    double *accp = (double *)malloc(sizeof(double) * N * 3);
+#pragma omp for schedule(static)
+    for (int64_t i = 0; i < C; ++i) {
+      const double *q = c->q + i * d;
+      double a = d == 3 ? q[1] : c->m.a, b = d == 3 ? q[2] : c->m.b;
+      double s0 = solve(c, q[0], a, b, c->data, acc0, 1);    /* MCMC.py:245-246, 468 */
+      double qp[3], XtX[9], Xi[9];
+      for (int p = 0; p < d; ++p) {                          /* MCMC.py:251-252 */
+        double pq[3] = {q[0], a, b};
+        pq[p] = pq[p] * (1 + fd);
+        qp[p] = pq[p];
+        solve(c, pq[0], pq[1], pq[2], NULL, accp + (int64_t)p * N, 1);
+      }
+      for (int p = 0; p < d; ++p)
+        for (int r = 0; r < d; ++r) {
+          double s = 0.0;
+          for (int32_t k = 0; k < N; ++k) {                  /* MCMC.py:264-265; perturbed denominator */
+            double xp = (accp[(int64_t)p * N + k] - acc0[k]) / (qp[p] * fd);
+            double xr = (accp[(int64_t)r * N + k] - acc0[k]) / (qp[r] * fd);
+            s += xp * xr;
+          }
+          XtX[p * d + r] = s;
+        }
+      double std2 = s0 / (double)(N - plen);                 /* MCMC.py:261 */
+      sym_inverse(XtX, d, Xi);
+      for (int e = 0; e < d * d; ++e) c->V[i * d * d + e] = std2 * Xi[e]; /* MCMC.py:266 */
+      c->std2[i] = std2;
+      c->ssq[i] = s0;
+    }
+    free(acc0);
+    free(accp);
+  }
+  c->iters_done = 0;
+  c->n_acc = c->n_eval = c->n_nonfinite = 0;
+  c->have_chains = 1;
+  return RSF_OK;
+}
+
+int rsf_mcmc_get_state(rsf_ctx *c, double *q, double *ssq, double *std2, double *V) {
+  if (!c) return fail(RSF_ERR_INVALID, "rsf_mcmc_get_state: NULL ctx");
+  if (!c->have_chains) return fail(RSF_ERR_STATE, "rsf_mcmc_get_state: call rsf_mcmc_init first");
+  const int d = c->mc.n_params;
+  const int64_t C = c->mc.n_chains;
+  if (q) memcpy(q, c->q, sizeof(double) * C * d);
+  if (ssq) memcpy(ssq, c->ssq, sizeof(double) * C);
+  if (std2) memcpy(std2, c->std2, sizeof(double) * C);
+  if (V) memcpy(V, c->V, sizeof(double) * C * d * d);
+  return RSF_OK;
+}
+
+int rsf_mcmc_set_state(rsf_ctx *c, const double *q, const double *ssq, const double *std2, const double *V) {
+  if (!c) return fail(RSF_ERR_INVALID, "rsf_mcmc_set_state: NULL ctx");
+  if (!c->have_chains) return fail(RSF_ERR_STATE, "rsf_mcmc_set_state: call rsf_mcmc_init first");
+  const int d = c->mc.n_params;
+  const int64_t C = c->mc.n_chains;
+  if (q) memcpy(c->q, q, sizeof(double) * C * d);
+  if (ssq) memcpy(c->ssq, ssq, sizeof(double) * C);
+  if (std2) memcpy(c->std2, std2, sizeof(double) * C);
+  if (V) memcpy(c->V, V, sizeof(double) * C * d * d);
+  return RSF_OK;
+}
+
+/* One chain, n_iters iterations of MCMC.py:494-527. */
+static void run_chain(rsf_ctx *c, int64_t i, int64_t n_iters, const double *zs, const double *us,
+                      const double *gs, double *tq, double *ts, uint8_t *ta, int64_t *acc_cnt,
+                      int64_t *eval_cnt, int64_t *nonfinite_cnt) {
+  const rsf_mcmc_config *mc = &c->mc;
+  const int d = mc->n_params;
+  const int64_t C = mc->n_chains;
+  const uint64_t gid = (uint64_t)(mc->chain_offset + i);
+  const double shape = 0.5 * (mc->n0 + (double)c->nout);     /* MCMC.py:158 */
+  double q[3], V[9], L[9];
+  double ssq = c->ssq[i], std2 = c->std2[i];
+  memcpy(q, c->q + i * d, sizeof(double) * d);
+  memcpy(V, c->V + i * d * d, sizeof(double) * d * d);
+  for (int64_t n = 0; n < n_iters; ++n) {
+    const uint32_t it = (uint32_t)(c->iters_done + n);
+    double z[4] = {0, 0, 0, 0}, qn[3];
+    /* proposal, MCMC.py:497 (d == 1: q + sqrt(V) z) */
+    if (zs) {
+      for (int p = 0; p < d; ++p) z[p] = zs[(n * C + i) * d + p];
+    } else {
+      uint32_t w[4];
+      draw_words(mc->seed, gid, it, SLOT_Z01, w);
+      normal_pair(w, &z[0], &z[1]);
+      if (d > 2) { draw_words(mc->seed, gid, it, SLOT_Z2, w); normal_pair(w, &z[2], &z[3]); }
+    }
+    chol_lower(V, d, L);
+    for (int p = 0; p < d; ++p) {
+      double s = q[p];
+      for (int r = 0; r <= p; ++r) s += L[p * d + r] * z[r];
+      qn[p] = s;
+    }
+    /* acceptreject, MCMC.py:318-333 */
+    int inb = 1, accept = 0;
+    for (int p = 0; p < d; ++p) inb = inb && (qn[p] > mc->lo[p]) && (qn[p] < mc->hi[p]);
+    if (inb) {
+      double ssqn = ssq_of(c, qn, d);
+      double u;
+      if (us) u = us[n * C + i];
+      else { uint32_t w[4]; draw_words(mc->seed, gid, it, SLOT_U, w); u = u53(w[0], w[1]); }
+      double logalpha = 0.5 * (ssq - ssqn) / std2;
+      if (logalpha > 0.0) logalpha = 0.0;                    /* np.clip(., -inf, 0) */
+      accept = logalpha > log(u);                            /* NaN => False */
+      ++*eval_cnt;
+      if (!isfinite(ssqn)) ++*nonfinite_cnt;
+      if (accept) { ssq = ssqn; memcpy(q, qn, sizeof(double) * d); ++*acc_cnt; }
+    }
+    /* update_standard_deviation, MCMC.py:158-160 (uses the post-accept SSq) */
+    {
+      double bval = 0.5 * (mc->n0 * std2 + ssq);
+      double g = gs ? gs[n * C + i] : gamma_draw(mc->seed, gid, it, shape);
+      std2 = 1.0 / (g * (1.0 / bval));
+    }
+    if (tq) memcpy(tq + (n * C + i) * d, q, sizeof(double) * d);
+    if (ts) ts[n * C + i] = std2;
+    if (ta) ta[n * C + i] = (uint8_t)accept;
+    /* adaptation, MCMC.py:523-527 with update_covariance_matrix :200-204 */
+    if (mc->adapt_mode != RSF_ADAPT_NONE) {
+      double *wr = c->wref + i * d, *ws = c->wsum + i * d, *wq = c->wsq + i * d * d;
+      for (int p = 0; p < d; ++p) {
+        ws[p] += q[p] - wr[p];
+        for (int r = 0; r < d; ++r) wq[p * d + r] += (q[p] - wr[p]) * (q[r] - wr[r]);
+      }
+      c->wn[i] += 1;
+      if ((c->iters_done + n + 1) % mc->adapt_interval == 0) {
+        const double nn = (double)c->wn[i];
+        double cov[9], Vn[9], Ln[9];
+        if (c->wn[i] >= 2) {
+          for (int p = 0; p < d; ++p)
+            for (int r = 0; r < d; ++r)
+              cov[p * d + r] = (wq[p * d + r] - ws[p] * ws[r] / nn) / (nn - 1.0); /* np.cov, ddof=1 */
+          if (mc->adapt_mode == RSF_ADAPT_REFERENCE_DICT) {
+            /* d := len(qpriors.keys()) = 2; the Cholesky FACTOR becomes the next covariance */
+            Vn[0] = 2.38 * 2.38 / 2.0 * cov[0];
+            if (chol_lower(Vn, 1, Ln)) V[0] = Ln[0];
+          } else {
+            for (int e = 0; e < d * d; ++e) Vn[e] = 2.38 * 2.38 / (double)d * cov[e];
+            if (chol_lower(Vn, d, Ln)) memcpy(V, Vn, sizeof(double) * d * d);
+          }
+        }
+        c->wn[i] = 0;
+        for (int p = 0; p < d; ++p) { wr[p] = q[p]; ws[p] = 0.0; }
+        for (int e = 0; e < d * d; ++e) wq[e] = 0.0;
+      }
+    }
+  }
+  c->ssq[i] = ssq;
+  c->std2[i] = std2;
+  memcpy(c->q + i * d, q, sizeof(double) * d);
+  memcpy(c->V + i * d * d, V, sizeof(double) * d * d);
+}
+
+static int run_all(rsf_ctx *c, int64_t n_iters, const double *z, const double *u, const double *g,
+                   double *tq, double *ts, uint8_t *ta) {
+  if (!c || n_iters < 0) return fail(RSF_ERR_INVALID, "rsf_mcmc_run: bad argument");
+  if (!c->have_chains) return fail(RSF_ERR_STATE, "rsf_mcmc_run: call rsf_mcmc_init first");
+  int64_t a = 0, e = 0, nf = 0;
+  int nt = nthreads(c);
+  (void)nt;
+#pragma omp parallel for schedule(static) reduction(+ : a, e, nf) num_threads(nt)
+  for (int64_t i = 0; i < c->mc.n_chains; ++i) run_chain(c, i, n_iters, z, u, g, tq, ts, ta, &a, &e, &nf);
+  c->n_acc += a; c->n_eval += e; c->n_nonfinite += nf;
+  c->iters_done += n_iters;
+  return RSF_OK;
+}
+
+int rsf_mcmc_run(rsf_ctx *c, int64_t n_iters, double *tq, double *ts, uint8_t *ta) {
+  return run_all(c, n_iters, NULL, NULL, NULL, tq, ts, ta);
+}
+
+int rsf_mcmc_replay(rsf_ctx *c, int64_t n_iters, const double *z, const double *u, const double *g,
+                    double *tq, double *ts, uint8_t *ta) {
+  if (!z || !u || !g) return fail(RSF_ERR_INVALID, "rsf_mcmc_replay: z, u and g are required");
+  return run_all(c, n_iters, z, u, g, tq, ts, ta);
+}
+
+int rsf_mcmc_stats(rsf_ctx *c, int64_t *n_acc, int64_t *n_eval, int64_t *n_nonfinite, int64_t *n_done) {
+  if (!c) return fail(RSF_ERR_INVALID, "rsf_mcmc_stats: NULL ctx");
+  if (!c->have_chains) return fail(RSF_ERR_STATE, "rsf_mcmc_stats: call rsf_mcmc_init first");
+  if (n_acc) *n_acc = c->n_acc;
+  if (n_eval) *n_eval = c->n_eval;
+  if (n_nonfinite) *n_nonfinite = c->n_nonfinite;
+  if (n_done) *n_done = c->iters_done;
+  return RSF_OK;
+}
+
+int rsf_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
+  if (!ctr || !key || !out) return fail(RSF_ERR_INVALID, "rsf_philox4x32_10: NULL argument");
+  philox_block(ctr, key, out);
+  return RSF_OK;
+}
+
+int rsf_mcmc_draws(uint64_t seed, int64_t chain, int64_t iteration, int32_t d, double shape, double *z,
+                   double *u, double *g) {
+  if (d < 1 || d > 3) return fail(RSF_ERR_INVALID, "rsf_mcmc_draws: n_params out of range");
+  uint32_t w[4];
+  double zz[4] = {0, 0, 0, 0};
+  draw_words(seed, (uint64_t)chain, (uint32_t)iteration, SLOT_Z01, w);
+  normal_pair(w, &zz[0], &zz[1]);
+  if (d > 2) { draw_words(seed, (uint64_t)chain, (uint32_t)iteration, SLOT_Z2, w); normal_pair(w, &zz[2], &zz[3]); }
+  if (z) for (int p = 0; p < d; ++p) z[p] = zz[p];
+  if (u) { draw_words(seed, (uint64_t)chain, (uint32_t)iteration, SLOT_U, w); *u = u53(w[0], w[1]); }
+  if (g) *g = gamma_draw(seed, (uint64_t)chain, (uint32_t)iteration, shape);
+  return RSF_OK;
+}

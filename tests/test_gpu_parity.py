@@ -1,0 +1,258 @@
+"""
+GPU parity tests: the HIP path (through the C ABI) against the CPU oracle on the same seeded
+inputs.  Tier-1 tolerance (BASELINE.json north_star): float64 agreement to rtol 1e-9 on the
+trajectory, the sum of squares and the log-likelihood -0.5*SSq/sigma^2.
+"""
+import numpy as np
+import pytest
+
+from conftest import synthetic_data
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-9
+
+
+def _models(oracle_mod, n, substeps=1, damping=True, t1=50.0):
+    m = oracle_mod.ModelSpec(n, 0.0, t1, substeps)
+    m.RadiationDamping = damping
+    return m
+
+
+def _traj_err(a, b):
+    scale = np.abs(b).max(axis=0)
+    return (np.abs(a - b).max(axis=0) / scale).max()
+
+
+def test_backend_and_devices(gpu_engine):
+    assert gpu_engine.lib.rsf_backend() == b"hip-gfx950"
+    assert gpu_engine.lib.rsf_device_count() >= 1
+
+
+def test_philox_known_answers_on_device(gpu_engine):
+    # Random123 kat_vectors, philox4x32-10
+    e = gpu_engine
+    assert e.philox([0, 0, 0, 0], [0, 0]) == [0x6627E8D5, 0xE169C58D, 0xBC57AC4C, 0x9B00DBD8]
+    assert e.philox([0xFFFFFFFF] * 4, [0xFFFFFFFF] * 2) == [0x408F276D, 0x41C83B0E, 0xA20BC7C6, 0x6D5451FD]
+    assert e.philox([0x243F6A88, 0x85A308D3, 0x13198A2E, 0x03707344], [0xA4093822, 0x299F31D0]) == \
+        [0xD16CFE09, 0x94FDCCEB, 0x5001E420, 0x24126EA1]
+
+
+def test_device_variates_match_oracle(gpu_engine, cpu_engine):
+    for chain, it in ((0, 0), (5, 17), (2 ** 33 + 7, 123456), (65535, 999)):
+        zg, ug, gg = gpu_engine.draws(2025, chain, it, 3, 250.005)
+        zc, uc, gc = cpu_engine.draws(2025, chain, it, 3, 250.005)
+        np.testing.assert_allclose(zg, zc, rtol=1e-12, atol=1e-14)
+        assert ug == uc
+        np.testing.assert_allclose(gg, gc, rtol=1e-12)
+
+
+@pytest.mark.parametrize("n,substeps,damping", [(500, 1, True), (500, 1, False), (500, 3, True), (2000, 1, True), (4000, 2, True), (37, 1, True)])
+def test_forward_trajectory_and_ssq(gpu_engine, cpu_engine, oracle_mod, n, substeps, damping):
+    m = _models(oracle_mod, n, substeps, damping)
+    rng = np.random.default_rng(n + substeps)
+    C = 203
+    dc = rng.uniform(50.0, 9000.0, C)
+    dc[:4] = [100.0, 1000.0, 5000.0, 9999.0]
+    a = rng.uniform(0.008, 0.016, C)
+    b = a + rng.uniform(-0.004, 0.008, C)
+    for e in (gpu_engine, cpu_engine):
+        assert e.set_model(m, substeps) == m.nout
+    data = synthetic_data(cpu_engine)
+    for kw in (dict(), dict(a=a, b=b)):
+        sg, ag = gpu_engine.forward(dc, data=data, want_ssq=True, want_acc=True, **kw)
+        sc, ac = cpu_engine.forward(dc, data=data, want_ssq=True, want_acc=True, **kw)
+        assert _traj_err(ag, ac) < RTOL
+        np.testing.assert_allclose(sg, sc, rtol=RTOL)
+        # SSq-only and trajectory-only launches are separate kernel instantiations
+        s2, _ = gpu_engine.forward(dc, data=data, want_ssq=True, want_acc=False, **kw)
+        _, a2 = gpu_engine.forward(dc, want_acc=True, **kw)
+        np.testing.assert_array_equal(s2, sg)
+        np.testing.assert_array_equal(a2, ag)
+
+
+def test_forward_edge_sizes(gpu_engine, cpu_engine, oracle_mod):
+    m = _models(oracle_mod, 500)
+    for e in (gpu_engine, cpu_engine):
+        e.set_model(m, 1)
+    for C in (1, 63, 64, 65, 256, 257):
+        dc = np.linspace(300.0, 3000.0, C)
+        _, ag = gpu_engine.forward(dc)
+        _, ac = cpu_engine.forward(dc)
+        assert ag.shape == (500, C)
+        assert _traj_err(ag, ac) < RTOL
+    # stiff corner: fixed-step RK4 blows up for tiny Dc; both sides must agree it is non-finite
+    data = synthetic_data(cpu_engine)
+    sg, _ = gpu_engine.forward([0.05, 0.2, 1000.0], data=data, want_ssq=True, want_acc=False)
+    sc, _ = cpu_engine.forward([0.05, 0.2, 1000.0], data=data, want_ssq=True, want_acc=False)
+    assert (np.isfinite(sg) == np.isfinite(sc)).all() and not np.isfinite(sg[0])
+
+
+def test_forward_against_reference_golden(gpu_engine, oracle_mod, golden):
+    """Tier 2: the GPU trajectory converges to the reference's dop853 output at 16x per halving."""
+    g = golden.npz("forward")
+    table = {500: {1: 3.6e-4, 2: 2.2e-5, 4: 1.4e-6, 8: 8.4e-8}, 2000: {1: 1.4e-6, 2: 8.5e-8, 4: 5.3e-9}}
+    for n, ladder in table.items():
+        ref = np.stack([g[f"n{n}_dc{dc:g}"] for dc in (100.0, 1000.0, 5000.0)], axis=1)
+        prev = None
+        for S, bound in ladder.items():
+            gpu_engine.set_model(_models(oracle_mod, n, S), S)
+            _, acc = gpu_engine.forward([100.0, 1000.0, 5000.0])
+            err = _traj_err(acc, ref)
+            assert err <= 2 * bound, (n, S, err)
+            if prev is not None and err > 5e-9:
+                assert 12 <= prev / err <= 20, (n, S, prev / err)
+            prev = err
+
+
+@pytest.mark.parametrize("prior_len", [3, 2])
+def test_initial_covariance(gpu_engine, cpu_engine, oracle_mod, prior_len):
+    m = _models(oracle_mod, 500)
+    for e in (gpu_engine, cpu_engine):
+        e.set_model(m, 1)
+    data = synthetic_data(cpu_engine)
+    q0 = np.linspace(400.0, 2500.0, 70).reshape(-1, 1)
+    for e in (gpu_engine, cpu_engine):
+        e.mcmc_init(q0, data, [0.0], [1e4], seed=1, prior_len=prior_len)
+    qg, sg, dg, Vg = gpu_engine.get_state()
+    qc, sc, dc_, Vc = cpu_engine.get_state()
+    np.testing.assert_array_equal(qg, qc)
+    np.testing.assert_allclose(sg, sc, rtol=RTOL)
+    np.testing.assert_allclose(dg, dc_, rtol=RTOL)
+    # Vstart divides by a forward difference with relative step 1e-6 (MCMC.py:251): rounding noise of
+    # ~1e-16 in acc is amplified by ~1e6..1e7, so agreement is limited to ~1e-7
+    np.testing.assert_allclose(Vg, Vc, rtol=2e-6)
+
+
+def _run_pair(gpu, cpu, n_iters, C, q0, data, lo, hi, **kw):
+    for e in (gpu, cpu):
+        e.mcmc_init(q0, data, lo, hi, **kw)
+    gpu.set_state(*cpu.get_state())  # identical start (see test_initial_covariance for why)
+    return gpu.mcmc_run(n_iters), cpu.mcmc_run(n_iters)
+
+
+def _assert_chains_match(tg, tc, min_same=0.995):
+    (qg, sg, ag), (qc, sc, ac) = tg, tc
+    same = (ag == ac).all(axis=0)
+    # a chain may legitimately fork when |log alpha - log u| is at rounding level; it must be rare
+    assert same.mean() >= min_same, f"{(~same).sum()} of {same.size} chains forked"
+    np.testing.assert_allclose(qg[:, same], qc[:, same], rtol=RTOL)
+    np.testing.assert_allclose(sg[:, same], sc[:, same], rtol=RTOL)
+    return same
+
+
+@pytest.mark.parametrize("n,C,adapt", [(500, 300, "none"), (500, 130, "reference_dict"), (500, 130, "am"), (2000, 70, "none")])
+def test_mcmc_run_matches_oracle(gpu_engine, cpu_engine, oracle_mod, n, C, adapt):
+    m = _models(oracle_mod, n)
+    for e in (gpu_engine, cpu_engine):
+        e.set_model(m, 1)
+    data = synthetic_data(cpu_engine)
+    q0 = np.full((C, 1), 1000.0)
+    tg, tc = _run_pair(gpu_engine, cpu_engine, 40, C, q0, data, [0.0], [1e4], seed=2025, chain_offset=12345,
+                       prior_len=3 if adapt == "none" else 2, adapt_mode=adapt, adapt_interval=10)
+    _assert_chains_match(tg, tc)
+    sg, sc = gpu_engine.stats(), cpu_engine.stats()
+    assert sg["iters_done"] == sc["iters_done"] == 40
+    assert abs(sg["accepted"] - sc["accepted"]) <= 0.01 * C * 40
+    # log-likelihood -0.5*SSq/sigma^2 at the end state
+    _, ssg, s2g, Vg = gpu_engine.get_state()
+    _, ssc, s2c, Vc = cpu_engine.get_state()
+    same = (tg[2] == tc[2]).all(axis=0)
+    np.testing.assert_allclose((-0.5 * ssg / s2g)[same], (-0.5 * ssc / s2c)[same], rtol=RTOL)
+    np.testing.assert_allclose(Vg[same], Vc[same], rtol=1e-8)
+
+
+def test_mcmc_continuation_equals_single_launch(gpu_engine, oracle_mod):
+    """Counter-based RNG + persistent state: 3 launches of 7 iterations == 1 launch of 21."""
+    m = _models(oracle_mod, 500)
+    gpu_engine.set_model(m, 1)
+    data = synthetic_data(gpu_engine)
+    q0 = np.full((100, 1), 900.0)
+    gpu_engine.mcmc_init(q0, data, [0.0], [1e4], seed=3, prior_len=2, adapt_mode="reference_dict", adapt_interval=5)
+    one = gpu_engine.mcmc_run(21)
+    gpu_engine.mcmc_init(q0, data, [0.0], [1e4], seed=3, prior_len=2, adapt_mode="reference_dict", adapt_interval=5)
+    parts = [gpu_engine.mcmc_run(7) for _ in range(3)]
+    for k in range(3):
+        np.testing.assert_array_equal(np.concatenate([p[k] for p in parts]), one[k])
+
+
+def test_out_of_bounds_proposals_skip_the_solve(gpu_engine, cpu_engine, oracle_mod):
+    m = _models(oracle_mod, 500)
+    for e in (gpu_engine, cpu_engine):
+        e.set_model(m, 1)
+    data = synthetic_data(cpu_engine)
+    C = 128
+    tg, tc = _run_pair(gpu_engine, cpu_engine, 30, C, np.full((C, 1), 1000.0), data, [980.0], [1020.0], seed=11, prior_len=3)
+    _assert_chains_match(tg, tc)
+    sg, sc = gpu_engine.stats(), cpu_engine.stats()
+    assert sg["evaluated"] == sc["evaluated"] < C * 30  # some proposals left the box: no forward solve for them
+    assert (tg[0] > 980.0).all() and (tg[0] < 1020.0).all()
+
+
+def test_three_parameter_chains(gpu_engine, cpu_engine, oracle_mod):
+    """Extension (BASELINE config 5): joint (Dc, a, b)."""
+    m = _models(oracle_mod, 500)
+    for e in (gpu_engine, cpu_engine):
+        e.set_model(m, 1)
+    data = synthetic_data(cpu_engine)
+    C = 96
+    q0 = np.tile([1000.0, 0.011, 0.014], (C, 1))
+    lo, hi = [0.0, 0.005, 0.005], [1e4, 0.02, 0.03]
+    tg, tc = _run_pair(gpu_engine, cpu_engine, 25, C, q0, data, lo, hi, seed=5, adapt_mode="am", adapt_interval=10)
+    same = _assert_chains_match(tg, tc, min_same=0.97)
+    assert same.sum() > 0 and tg[0].shape == (25, C, 3)
+
+
+def test_replay_of_reference_variates(gpu_engine, golden, oracle_mod):
+    """The reference's own recorded chain (tests/golden/replay_*.npz): feeding the GPU kernel the variates the
+    reference consumed reproduces its accept decisions and samples up to the RK4-vs-dop853 difference."""
+    for tag, S in (("list", 8), ("dict", 8), ("tightbox", 8)):
+        g, meta = golden.npz("replay_" + tag), golden.json("replay_" + tag)
+        m = _models(oracle_mod, meta["nsteps"], S)
+        gpu_engine.set_model(m, S)
+        lo, hi = (meta["prior"][1], meta["prior"][2]) if isinstance(meta["prior"], list) else (meta["prior"]["1"], meta["prior"]["2"])
+        gpu_engine.mcmc_init([[meta["qstart"]]], g["data"], [lo], [hi], prior_len=3 if isinstance(meta["prior"], list) else 2,
+                             adapt_mode="reference_dict" if meta["prior_is_dict"] else "none", adapt_interval=meta["adapt_interval"])
+        q, ssq, std2, V = gpu_engine.get_state()
+        np.testing.assert_allclose(std2[0], meta["std2_0"], rtol=1e-6)
+        np.testing.assert_allclose(ssq[0], meta["ssq0"], rtol=1e-6)
+        np.testing.assert_allclose(V[0, 0, 0], meta["vstart"], rtol=1e-4)
+        gpu_engine.set_state(V=[[[meta["vstart"]]]], std2=[meta["std2_0"]], ssq=[meta["ssq0"]])
+        n = len(g["z"])
+        u = np.where(np.isnan(g["u"]), 1.0, g["u"])
+        tq, ts, ta = gpu_engine.mcmc_replay(g["z"].reshape(n, 1, 1), u.reshape(n, 1), g["g"].reshape(n, 1))
+        nb = meta["nburn"]
+        np.testing.assert_allclose(tq[nb - 1:, 0, 0], g["qparams_kept"][0], rtol=1e-6)
+        np.testing.assert_allclose(ts[nb - 1:, 0], g["std2_kept"], rtol=1e-5)
+
+
+def test_device_memory_path_and_full_size_properties(pkg, oracle_mod):
+    """BASELINE config 1 size (65 536 chains, nsteps 500) with device-resident buffers: determinism, and
+    shard invariance — splitting the chains into two ctxs by global id gives the identical pool."""
+    import torch
+
+    m = _models(oracle_mod, 500)
+    C = 65536
+    with pkg.Engine(mem="host") as e:
+        e.set_model(m, 1)
+        data = synthetic_data(e)
+    q0 = torch.full((C, 1), 1000.0, dtype=torch.float64, device="cuda")
+
+    def run(off, cnt):
+        with pkg.Engine(mem="device") as e:
+            e.set_model(m, 1)
+            e.mcmc_init(q0[off:off + cnt], data, [0.0], [1e4], seed=2025, chain_offset=off, prior_len=3)
+            tq, ts, ta = e.mcmc_run(5)
+            e.sync()
+            return tq.cpu().numpy(), ts.cpu().numpy(), ta.cpu().numpy(), e.stats()
+
+    full = run(0, C)
+    again = run(0, C)
+    for k in range(3):
+        np.testing.assert_array_equal(full[k], again[k])
+    lo_half, hi_half = run(0, C // 2), run(C // 2, C // 2)
+    for k in range(3):
+        np.testing.assert_array_equal(np.concatenate([lo_half[k], hi_half[k]], axis=1), full[k])
+    assert full[3]["evaluated"] == 5 * C
+    acc_rate = full[3]["accepted"] / (5 * C)
+    assert 0.3 < acc_rate < 0.95
+    assert np.isfinite(full[0]).all() and (full[1] > 0).all()
