@@ -110,6 +110,29 @@ def bind(lib):
 _lib = None
 
 
+def hip_runtime_path():
+    """The ONE HIP runtime this process uses.  librsf_hip.so is linked without a runtime dependency
+    because two HIP/HSA runtimes in a process cannot both own the GPU: PyTorch's ROCm wheel bundles
+    its own libamdhip64.so (no SONAME, so the loader does not unify it with /opt/rocm's), and the
+    engine shares device memory and streams with torch.  Order: $RSF_HIP_RUNTIME, torch's bundled
+    runtime, then $ROCM_PATH or /opt/rocm."""
+    env = os.environ.get("RSF_HIP_RUNTIME")
+    if env:
+        return env
+    try:
+        import torch
+
+        cand = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            return cand
+    except ImportError:
+        pass
+    for root in (os.environ.get("ROCM_PATH"), "/opt/rocm"):
+        if root and os.path.exists(os.path.join(root, "lib", "libamdhip64.so")):
+            return os.path.join(root, "lib", "libamdhip64.so")
+    raise RsfError(-2, "no HIP runtime (libamdhip64.so) found; set RSF_HIP_RUNTIME")
+
+
 def load():
     """The product library (HIP).  Fails loudly; never substitutes a CPU implementation."""
     global _lib
@@ -117,6 +140,7 @@ def load():
         if not os.path.exists(LIB_PATH):
             raise RsfError(-2, f"{LIB_PATH} is not built; run `python -c 'import __graft_entry__ as g; g.build()'` "
                                "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+        ctypes.CDLL(hip_runtime_path(), mode=ctypes.RTLD_GLOBAL)  # resolves the library's hip* symbols
         lib = bind(ctypes.CDLL(LIB_PATH))
         if lib.rsf_version() != ABI_VERSION:
             raise RsfError(-1, f"ABI version mismatch: library {lib.rsf_version()}, binding {ABI_VERSION}")
