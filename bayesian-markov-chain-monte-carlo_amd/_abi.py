@@ -11,7 +11,8 @@ import os
 from ctypes import POINTER, c_char_p, c_double, c_int, c_int32, c_int64, c_uint8, c_uint32, c_uint64, c_void_p
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "csrc", "librsf_hip.so")
+# RSF_HIP_LIB: alternative build of the same HIP library (kernel A/B experiments); never a CPU library
+LIB_PATH = os.environ.get("RSF_HIP_LIB") or os.path.join(HERE, "csrc", "librsf_hip.so")
 
 ABI_VERSION = 1
 OK = 0

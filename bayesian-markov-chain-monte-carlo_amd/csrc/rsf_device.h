@@ -11,6 +11,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "rsf_math.h"
+
 namespace rsf {
 
 // ---------------------------------------------------------------------------------------------
@@ -29,55 +31,179 @@ struct Consts {
   int32_t nchunks;                // ceil((nout-1)/kc); 1 => tables stay resident in LDS
 };
 
-// per-lane proposal constants, hoisted out of the time loop
+// per-lane proposal constants, hoisted out of the time loop (V_ref folded in where it multiplies)
 struct Lane {
   double inv_dc;  // 1/Dc
+  double xs;      // V_ref/Dc: argument scale of the log, RateStateModel.py:336
   double kprime;  // 1e-2*10/Dc, RateStateModel.py:324
+  double kpv;     // kprime*V_ref
   double inv_a;   // 1/a
+  double via;     // V_ref/a
   double b;
+  double boa;     // b/a
+  double tc;      // -mu_ref/a
 };
 
-__device__ __forceinline__ Lane make_lane(double dc, double a, double b) {
+__device__ __forceinline__ Lane make_lane(double dc, double a, double b, const Consts &K) {
   Lane L;
   L.inv_dc = 1.0 / dc;
+  L.xs = K.V_ref * L.inv_dc;
   L.kprime = (1e-2 * 10) / dc;
+  L.kpv = L.kprime * K.V_ref;
   L.inv_a = 1.0 / a;
+  L.via = K.V_ref * L.inv_a;
   L.b = b;
+  L.boa = b * L.inv_a;
+  L.tc = -K.mu_ref * L.inv_a;
   return L;
 }
 
 // ---------------------------------------------------------------------------------------------
 // RHS, RateStateModel.py:318-355.  y[2] (V) never feeds back, so only (mu, theta) are inputs.
+// Same quantities as the reference, regrouped so that every reciprocal is hoisted into Lane and
+// the slip rate appears only as w = v/V_ref = exp((mu-mu_ref)/a - (b/a) log(V_ref*theta/Dc)).
 // ---------------------------------------------------------------------------------------------
+struct Base {   // transcendental results at the start point of the RK4 step (stage 1)
+  double w;     // v/V_ref
+  double rth;   // 1/theta
+};
+
+// the part of the RHS after w = v/V_ref and 1/theta are known
 template <bool DAMP>
-__device__ __forceinline__ void rhs(double mu, double th, double vl, const Lane &L, const Consts &K,
-                                    double &d0, double &d1, double &d2) {
-  const double lg = log(K.V_ref * th * L.inv_dc);
-  const double temp = L.inv_a * (mu - K.mu_ref - L.b * lg);
-  const double v = K.V_ref * exp(temp);
-  d1 = 1.0 - v * th * L.inv_dc;                // ageing law
-  d0 = L.kprime * (vl - v);                    // spring loading
-  const double bt = L.b / th * d1;
-  const double va = v * L.inv_a;
+__device__ __forceinline__ void rhs_tail(double w, double rth, double th, double vl, const Lane &L,
+                                         const Consts &K, double &d0, double &d1, double &d2) {
+  d1 = __builtin_fma(-w, th * L.inv_dc, 1.0);        // ageing law: 1 - v*theta/Dc
+  d0 = __builtin_fma(-L.kpv, w, L.kprime * vl);      // spring loading: k'(V_l - v)
+  const double bt = (L.b * d1) * rth;                // b/theta * dtheta/dt
+  const double va = w * L.via;                       // v/a
   d2 = va * (d0 - bt);
-  if (DAMP) {                                  // one fixed-point pass, RateStateModel.py:349-353
-    d0 = d0 - K.k1 * d2;
+  if (DAMP) {                                        // one fixed-point pass, RateStateModel.py:349-353
+    d0 = __builtin_fma(-K.k1, d2, d0);
     d2 = va * (d0 - bt);
   }
 }
 
-// one classical RK4 step of size h; vl0/vlm/vl1 = V_l at t, t+h/2, t+h
+// w = v/V_ref and 1/theta by full evaluation
+__device__ __forceinline__ void rhs_full(double mu, double th, const Lane &L, Base &B) {
+#ifdef RSF_MATH_OCML
+  B.w = ::exp(__builtin_fma(-L.boa, ::log(th * L.xs), __builtin_fma(mu, L.inv_a, L.tc)));
+  B.rth = 1.0 / th;
+#else
+  B.w = fm::exp(__builtin_fma(-L.boa, fm::log(th * L.xs), __builtin_fma(mu, L.inv_a, L.tc)));
+  B.rth = fm::rcp(th);
+#endif
+}
+
+// One classical RK4 step of size h; vl0/vlm/vl1 = V_l at t, t+h/2, t+h.
+//
+// Stage 1 evaluates log / exp / reciprocal in full and keeps the results B at (mu, th).  Stages
+// 2-4 are at (mu + dmu, th + dth) with small increments, so with rho = dth/th and
+// dlt = dmu/a - (b/a) log1p(rho):
+//     w' = w * exp(dlt),     1/th' = (1/th) / (1 + rho),
+// evaluated by short series — the same function of (mu', th') to rounding as long as |rho| and
+// |dmu/a| stay below 2^-8 (truncation < 1e-17), which holds for the step sizes and Dc range the
+// sampler visits.  The code is straight-line (a lone wave per SIMD pays ~9 cycles per dependent
+// fp64 op and a full issue slot per branch/nop, measured with tools/microbench_fp64.hip): the
+// largest increment of the step is tracked with v_max_f64 and checked ONCE per step; if any
+// lane exceeded the bound the step is redone with full evaluations (rk4_step_full, cold path).
+template <bool DAMP>
+__device__ __forceinline__ void rk4_step_full(double &mu, double &th, double &V, double vl0, double vlm,
+                                                        double vl1, const Lane &L, const Consts &K) {
+  double k0 = 0.0, k1 = 0.0, s0 = 0.0, s1 = 0.0, s2 = 0.0;
+#pragma nounroll
+  for (int s = 0; s < 4; ++s) {
+    const double c = s == 0 ? 0.0 : (s == 3 ? K.h : K.hh);
+    const double wgt = (s == 0 || s == 3) ? 1.0 : 2.0;
+    const double vl = s == 0 ? vl0 : (s == 3 ? vl1 : vlm);
+    const double th1 = __builtin_fma(c, k1, th);
+    Base F;
+    rhs_full(__builtin_fma(c, k0, mu), th1, L, F);
+    double d0, d1, d2;
+    rhs_tail<DAMP>(F.w, F.rth, th1, vl, L, K, d0, d1, d2);
+    s0 = __builtin_fma(wgt, d0, s0);
+    s1 = __builtin_fma(wgt, d1, s1);
+    s2 = __builtin_fma(wgt, d2, s2);
+    k0 = d0;
+    k1 = d1;
+  }
+  mu = __builtin_fma(K.h6, s0, mu);
+  th = __builtin_fma(K.h6, s1, th);
+  V = __builtin_fma(K.h6, s2, V);
+}
+
+// incremental stage: (w, 1/th) at (mu + dmu, th + dth) from B at (mu, th); updates the bound tracker
+__device__ __forceinline__ void incr_eval(double dmu, double dth, double th1, const Lane &L, const Base &B,
+                                          double &w, double &rth, double &big) {
+  const double rho = dth * B.rth;
+  const double dm = dmu * L.inv_a;
+  big = __builtin_fmax(big, __builtin_fmax(__builtin_fabs(rho), __builtin_fabs(dm)));
+  // log1p(rho) = rho - rho^2/2 + ... - rho^6/6              (next term < 2^-56/7)
+  double p = -1.0 / 6.0;
+  p = fm::hfma(p, rho, 1.0 / 5.0);
+  p = fm::hfma(p, rho, -1.0 / 4.0);
+  p = fm::hfma(p, rho, 1.0 / 3.0);
+  p = __builtin_fma(p, rho, -0.5);
+  p = __builtin_fma(p, rho, 1.0);
+  const double dlt = __builtin_fma(-L.boa, p * rho, dm);
+  // expm1(dlt) = dlt + dlt^2/2 + ... + dlt^7/5040          (next term < 1e-19 for |dlt| < 2^-6)
+  double e = 1.0 / 5040.0;
+  e = fm::hfma(e, dlt, 1.0 / 720.0);
+  e = fm::hfma(e, dlt, 1.0 / 120.0);
+  e = fm::hfma(e, dlt, 1.0 / 24.0);
+  e = fm::hfma(e, dlt, 1.0 / 6.0);
+  e = __builtin_fma(e, dlt, 0.5);
+  e = __builtin_fma(e, dlt, 1.0);
+  w = __builtin_fma(B.w, e * dlt, B.w);
+  // 1/th' from 1/th: first-order start (error rho^2 < 2^-16), two Newton steps (-> 2^-64)
+  rth = __builtin_fma(-rho, B.rth, B.rth);
+  double r = __builtin_fma(-th1, rth, 1.0);
+  rth = __builtin_fma(rth, r, rth);
+  r = __builtin_fma(-th1, rth, 1.0);
+  rth = __builtin_fma(rth, r, rth);
+}
+
 template <bool DAMP>
 __device__ __forceinline__ void rk4_step(double &mu, double &th, double &V, double vl0, double vlm,
                                          double vl1, const Lane &L, const Consts &K) {
+#ifdef RSF_NO_INCREMENTAL
   double a0, a1, a2, b0, b1, b2, c0, c1, c2, e0, e1, e2;
-  rhs<DAMP>(mu, th, vl0, L, K, a0, a1, a2);
-  rhs<DAMP>(mu + K.hh * a0, th + K.hh * a1, vlm, L, K, b0, b1, b2);
-  rhs<DAMP>(mu + K.hh * b0, th + K.hh * b1, vlm, L, K, c0, c1, c2);
-  rhs<DAMP>(mu + K.h * c0, th + K.h * c1, vl1, L, K, e0, e1, e2);
+  Base F;
+  rhs_full(mu, th, L, F);
+  rhs_tail<DAMP>(F.w, F.rth, th, vl0, L, K, a0, a1, a2);
+  double t = __builtin_fma(K.hh, a1, th);
+  rhs_full(__builtin_fma(K.hh, a0, mu), t, L, F);
+  rhs_tail<DAMP>(F.w, F.rth, t, vlm, L, K, b0, b1, b2);
+  t = __builtin_fma(K.hh, b1, th);
+  rhs_full(__builtin_fma(K.hh, b0, mu), t, L, F);
+  rhs_tail<DAMP>(F.w, F.rth, t, vlm, L, K, c0, c1, c2);
+  t = __builtin_fma(K.h, c1, th);
+  rhs_full(__builtin_fma(K.h, c0, mu), t, L, F);
+  rhs_tail<DAMP>(F.w, F.rth, t, vl1, L, K, e0, e1, e2);
   mu = mu + K.h6 * (a0 + 2.0 * b0 + 2.0 * c0 + e0);
   th = th + K.h6 * (a1 + 2.0 * b1 + 2.0 * c1 + e1);
   V = V + K.h6 * (a2 + 2.0 * b2 + 2.0 * c2 + e2);
+#else
+  double a0, a1, a2, b0, b1, b2, c0, c1, c2, e0, e1, e2, w, rth, big = 0.0;
+  Base B;
+  rhs_full(mu, th, L, B);
+  rhs_tail<DAMP>(B.w, B.rth, th, vl0, L, K, a0, a1, a2);
+  double dth = K.hh * a1;
+  incr_eval(K.hh * a0, dth, th + dth, L, B, w, rth, big);
+  rhs_tail<DAMP>(w, rth, th + dth, vlm, L, K, b0, b1, b2);
+  dth = K.hh * b1;
+  incr_eval(K.hh * b0, dth, th + dth, L, B, w, rth, big);
+  rhs_tail<DAMP>(w, rth, th + dth, vlm, L, K, c0, c1, c2);
+  dth = K.h * c1;
+  incr_eval(K.h * c0, dth, th + dth, L, B, w, rth, big);
+  rhs_tail<DAMP>(w, rth, th + dth, vl1, L, K, e0, e1, e2);
+  if (__builtin_expect(!(big < 0x1.0p-8), 0)) {   // some increment too large (or Inf): cold path, NaN passes through
+    rk4_step_full<DAMP>(mu, th, V, vl0, vlm, vl1, L, K);
+    return;
+  }
+  mu = mu + K.h6 * (a0 + 2.0 * b0 + 2.0 * c0 + e0);
+  th = th + K.h6 * (a1 + 2.0 * b1 + 2.0 * c1 + e1);
+  V = V + K.h6 * (a2 + 2.0 * b2 + 2.0 * c2 + e2);
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -124,7 +250,7 @@ __device__ __forceinline__ void integrate_chunk(const double *lds, const Consts 
 template <bool DAMP, bool WANT_SSQ, bool WANT_ACC, bool RESIDENT>
 __device__ __forceinline__ double solve(double *lds, const Consts &K, bool active, double dc, double a,
                                         double b, double *acc_out, int64_t stride) {
-  const Lane L = make_lane(dc, a, b);
+  const Lane L = make_lane(dc, a, b, K);
   double mu = K.mu0, th = dc / K.V_ref, V = K.V_ref;  // RateStateModel.py:367-377
   double ssq = 0.0;
   if (WANT_SSQ && active) {

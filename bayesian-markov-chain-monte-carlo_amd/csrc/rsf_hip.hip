@@ -93,14 +93,14 @@ __global__ void __launch_bounds__(kMaxBlock) init_kernel(Consts K, InitArgs A) {
   }
   rsf::Lane L[D + 1];
   double mu[D + 1], th[D + 1], V[D + 1], inv_den[D];
-  L[0] = rsf::make_lane(p0[0], p0[1], p0[2]);
+  L[0] = rsf::make_lane(p0[0], p0[1], p0[2], K);
   mu[0] = K.mu0; th[0] = p0[0] / K.V_ref; V[0] = K.V_ref;
 #pragma unroll
   for (int p = 0; p < D; ++p) {
     double pq[3] = {p0[0], p0[1], p0[2]};
     pq[p] = pq[p] * (1 + A.fd);
     inv_den[p] = 1.0 / (pq[p] * A.fd);  // perturbed value in the denominator, MCMC.py:264
-    L[p + 1] = rsf::make_lane(pq[0], pq[1], pq[2]);
+    L[p + 1] = rsf::make_lane(pq[0], pq[1], pq[2], K);
     mu[p + 1] = K.mu0; th[p + 1] = pq[0] / K.V_ref; V[p + 1] = K.V_ref;
   }
   double xtx[D * D];

@@ -1,0 +1,96 @@
+// rsf_math.h — fp64 log / exp / reciprocal for the RHS inner loop on gfx950.
+//
+// The kernel is bound by fp64 VALU issue (one wave64 v_fma_f64 occupies a SIMD for 4 cycles), so
+// the cost of an RK4 step is its fp64 instruction count.  OCML's log/exp/division are written for
+// <= 1 ulp over the whole double range with double-double arithmetic and special-case handling
+// (~110 fp64 instructions per RHS).  The RHS needs only ~1e-15 relative accuracy on positive,
+// normal arguments, so these versions use plain Horner evaluation:
+//   rcp  : v_rcp_f64 seed + Newton-Raphson                                (3-5 instructions)
+//   log  : frexp split to m in [sqrt(1/2), sqrt(2)), s = (m-1)/(m+1), 2*atanh(s) series in s^2
+//   exp  : k = rint(x*log2 e), r = x - k*ln2 (two-piece), Taylor in r, v_ldexp_f64
+// Non-finite behaviour that the sampler relies on is kept: log(x) is NaN for x <= 0 or NaN, and
+// NaN / +-inf inputs never produce a finite result (so a diverged trajectory still yields a
+// non-finite sum of squares and the proposal is rejected, as in the CPU restatement).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace rsf {
+namespace fm {
+
+// Horner step p*x + c with the coefficient c held in a register across the time loop.  Written
+// as one explicit 3-address v_fma_f64: left to itself hipcc (ROCm 7.2) selects the 2-address
+// v_fmac_f64 for these and then has to copy the loop-invariant coefficient first
+// (v_mov_b64 + v_fmac_f64 per term), which costs an extra issue slot per polynomial term.
+__device__ __forceinline__ double hfma(double p, double x, double c) {
+#ifdef RSF_NO_ASM_FMA
+  return __builtin_fma(p, x, c);
+#else
+  double r;
+  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(p), "v"(x), "v"(c));
+  return r;
+#endif
+}
+
+#ifndef RSF_RCP_NR_STEPS
+#define RSF_RCP_NR_STEPS 2
+#endif
+
+__device__ __forceinline__ double rcp(double x) {
+  double r = __builtin_amdgcn_rcp(x);  // v_rcp_f64: hardware seed
+#pragma unroll
+  for (int i = 0; i < RSF_RCP_NR_STEPS; ++i) {
+    const double e = __builtin_fma(-x, r, 1.0);
+    r = hfma(r, e, r);
+  }
+  return r;
+}
+
+__device__ __forceinline__ double log(double x) {
+  double m = __builtin_amdgcn_frexp_mant(x);  // [0.5, 1)
+  int e = __builtin_amdgcn_frexp_exp(x);
+  const bool low = m < 0.70710678118654752440;
+  m = low ? m + m : m;                         // [sqrt(1/2), sqrt(2))
+  e = low ? e - 1 : e;
+  const double f = m - 1.0;                    // exact
+  const double s = f * rcp(m + 1.0);
+  const double z = s * s;                      // <= 0.02944
+  // 2*atanh(s) = 2s + s*z*(2/3 + 2/5 z + 2/7 z^2 + ... + 2/21 z^9); truncation < 2.2e-19
+  double p = 2.0 / 21.0;
+  p = hfma(p, z, 2.0 / 19.0);
+  p = hfma(p, z, 2.0 / 17.0);
+  p = hfma(p, z, 2.0 / 15.0);
+  p = hfma(p, z, 2.0 / 13.0);
+  p = hfma(p, z, 2.0 / 11.0);
+  p = hfma(p, z, 2.0 / 9.0);
+  p = hfma(p, z, 2.0 / 7.0);
+  p = hfma(p, z, 2.0 / 5.0);
+  p = hfma(p, z, 2.0 / 3.0);
+  const double lm = __builtin_fma(s * z, p, s + s);
+  const double r = __builtin_fma((double)e, 0.69314718055994530942, lm);
+  return x > 0.0 ? r : __builtin_nan("");
+}
+
+__device__ __forceinline__ double exp(double x) {
+  const double k = __builtin_rint(x * 1.4426950408889634074);
+  double r = __builtin_fma(-k, 0x1.62e42fefa38p-1, x);      // ln2 high part: 42 significant bits, k*hi exact
+  r = __builtin_fma(-k, 0x1.ef35793c7673p-45, r);           // ln2 low part
+  // |r| <= 0.3466: Taylor to r^13/13!, truncation < 5e-18 relative
+  double p = 1.0 / 6227020800.0;
+  p = hfma(p, r, 1.0 / 479001600.0);
+  p = hfma(p, r, 1.0 / 39916800.0);
+  p = hfma(p, r, 1.0 / 3628800.0);
+  p = hfma(p, r, 1.0 / 362880.0);
+  p = hfma(p, r, 1.0 / 40320.0);
+  p = hfma(p, r, 1.0 / 5040.0);
+  p = hfma(p, r, 1.0 / 720.0);
+  p = hfma(p, r, 1.0 / 120.0);
+  p = hfma(p, r, 1.0 / 24.0);
+  p = hfma(p, r, 1.0 / 6.0);
+  p = __builtin_fma(p, r, 0.5);
+  p = __builtin_fma(p, r, 1.0);
+  p = __builtin_fma(p, r, 1.0);
+  return __builtin_amdgcn_ldexp(p, (int)k);  // v_cvt_i32_f64 saturates; v_ldexp_f64 over/underflows to inf/0
+}
+
+}  // namespace fm
+}  // namespace rsf

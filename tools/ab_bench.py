@@ -1,0 +1,68 @@
+#!/usr/bin/env python3
+"""
+A/B timing of kernel builds in ONE process with interleaved rounds (same device, same clocks).
+
+  python tools/ab_bench.py [--chains C] [--nsteps N] [--iters I] [--rounds R] name=path.so ...
+
+Each variant is a build of csrc/rsf_hip.hip (e.g. with -DRSF_NO_INCREMENTAL); "default" is the
+in-tree librsf_hip.so.  Prints median / min milliseconds per launch and ODE-steps*chains/s.
+"""
+import argparse
+import ctypes
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--chains", type=int, default=65536)
+    ap.add_argument("--nsteps", type=int, default=500)
+    ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--rounds", type=int, default=7)
+    ap.add_argument("variants", nargs="*")
+    args = ap.parse_args()
+
+    import torch
+
+    import bayesian_markov_chain_monte_carlo_amd as pkg
+    from bench import synthetic_problem
+
+    libs = {"default": pkg._abi.load()}
+    for v in args.variants:
+        name, path = v.split("=", 1)
+        libs[name] = pkg._abi.bind(ctypes.CDLL(os.path.abspath(path)))
+    model, data = synthetic_problem(args.nsteps)
+    C, ips = args.chains, args.iters
+    engines, traces = {}, (torch.empty((ips, C, 1), dtype=torch.float64, device="cuda"),
+                           torch.empty((ips, C), dtype=torch.float64, device="cuda"), None)
+    q0 = torch.full((C, 1), 1000.0, dtype=torch.float64, device="cuda")
+    for name, lib in libs.items():
+        e = pkg.Engine(lib=lib, mem="device")
+        e.set_model(model, 1)
+        e.mcmc_init(q0, data, [0.0], [1.0e4], seed=2025, prior_len=3)
+        e.mcmc_run(ips, out=traces)  # warm-up
+        engines[name] = e
+    torch.cuda.synchronize()
+    times = {n: [] for n in engines}
+    for _ in range(args.rounds):
+        for name, e in engines.items():
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            e.mcmc_run(ips, out=traces)
+            b.record()
+            torch.cuda.synchronize()
+            times[name].append(a.elapsed_time(b))
+    work = C * ips * args.nsteps
+    print(f"chains={C} nsteps={args.nsteps} iters/launch={ips} rounds={args.rounds}")
+    for name, t in times.items():
+        med, mn = float(np.median(t)), float(np.min(t))
+        print(f"  {name:16s} median {med:9.3f} ms  min {mn:9.3f} ms   {work / (med * 1e-3):.4e} steps*chains/s")
+
+
+if __name__ == "__main__":
+    main()

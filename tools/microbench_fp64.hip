@@ -1,0 +1,101 @@
+// microbench_fp64.hip — fp64 VALU issue / latency on gfx950 (diagnostic tool, not product code).
+// Each test runs ITERS x UNROLL instructions per wave in ILP independent dependency chains, with
+// W waves per SIMD (grid = 1024 SIMDs * W waves), and reports shader cycles per wave-instruction
+// (s_memtime) and the wall-clock equivalent.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <vector>
+
+#define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
+
+constexpr int ITERS = 60000;
+
+template <int OP, int ILP>
+__global__ void __launch_bounds__(256) bench(double *out, unsigned long long *cyc, unsigned long long *rt, double seed) {
+  double r[ILP];
+#pragma unroll
+  for (int i = 0; i < ILP; ++i) r[i] = seed + i * 1e-3 + threadIdx.x * 1e-6;
+  const double a = 1.0000001, b = 1e-9;
+  unsigned long long t0, t1, r0, r1;
+  asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(r0)::"memory");
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");
+  for (int it = 0; it < ITERS; ++it) {
+#pragma unroll
+    for (int u = 0; u < 16 / ILP; ++u) {
+#pragma unroll
+      for (int i = 0; i < ILP; ++i) {
+        if (OP == 0) asm volatile("v_fma_f64 %0, %0, %1, %2" : "+v"(r[i]) : "v"(a), "v"(b));
+        if (OP == 1) asm volatile("v_mul_f64 %0, %0, %1" : "+v"(r[i]) : "v"(a));
+        if (OP == 2) asm volatile("v_add_f64 %0, %0, %1" : "+v"(r[i]) : "v"(b));
+        if (OP == 3) asm volatile("v_rcp_f64 %0, %0" : "+v"(r[i]));
+        if (OP == 4) asm volatile("v_ldexp_f64 %0, %0, 0" : "+v"(r[i]));
+        if (OP == 5) asm volatile("v_frexp_mant_f64 %0, %0" : "+v"(r[i]));
+        if (OP == 6) asm volatile("v_rndne_f64 %0, %0" : "+v"(r[i]));
+        if (OP == 7) asm volatile("v_mov_b64 %0, %0" : "+v"(r[i]));
+        if (OP == 8) { float f = (float)r[i]; asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(f)); r[i] = f; }
+        if (OP == 9) asm volatile("v_fmac_f64 %0, %1, %2" : "+v"(r[i]) : "v"(a), "v"(b));
+        if (OP == 10) asm volatile("s_nop 0\n\tv_fma_f64 %0, %0, %1, %2" : "+v"(r[i]) : "v"(a), "v"(b));
+        if (OP == 11) { int lo = __double2loint(r[i]); asm volatile("v_cndmask_b32 %0, %0, %0, vcc" : "+v"(lo)); r[i] = __hiloint2double(__double2hiint(r[i]), lo); }
+      }
+    }
+  }
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1)::"memory");
+  asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(r1)::"memory");
+  double s = 0;
+#pragma unroll
+  for (int i = 0; i < ILP; ++i) s += r[i];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+  if (threadIdx.x == 0) { cyc[blockIdx.x] = t1 - t0; rt[blockIdx.x] = r1 - r0; }
+}
+
+template <int OP, int ILP>
+int run(const char *name, int waves_per_simd) {
+  const int blocks = 256 * waves_per_simd;  // 256 CUs, 256-thread blocks = one wave per SIMD per block
+  double *out;
+  unsigned long long *cyc, *rt;
+  CHECK(hipMalloc(&out, sizeof(double) * blocks * 256));
+  CHECK(hipMalloc(&cyc, sizeof(unsigned long long) * blocks));
+  CHECK(hipMalloc(&rt, sizeof(unsigned long long) * blocks));
+  hipEvent_t e0, e1;
+  CHECK(hipEventCreate(&e0));
+  CHECK(hipEventCreate(&e1));
+  hipLaunchKernelGGL((bench<OP, ILP>), dim3(blocks), dim3(256), 0, nullptr, out, cyc, rt, 1.0);
+  CHECK(hipDeviceSynchronize());
+  CHECK(hipEventRecord(e0));
+  hipLaunchKernelGGL((bench<OP, ILP>), dim3(blocks), dim3(256), 0, nullptr, out, cyc, rt, 1.0);
+  CHECK(hipEventRecord(e1));
+  CHECK(hipEventSynchronize(e1));
+  float ms;
+  CHECK(hipEventElapsedTime(&ms, e0, e1));
+  std::vector<unsigned long long> h(blocks);
+  CHECK(hipMemcpy(h.data(), cyc, sizeof(unsigned long long) * blocks, hipMemcpyDeviceToHost));
+  std::vector<unsigned long long> hr(blocks);
+  CHECK(hipMemcpy(hr.data(), rt, sizeof(unsigned long long) * blocks, hipMemcpyDeviceToHost));
+  double mean = 0, mrt = 0;
+  for (auto v : h) mean += v;
+  for (auto v : hr) mrt += v;
+  mean /= blocks;
+  mrt /= blocks;
+  const double n = (double)ITERS * 16;
+  printf("%-14s ILP=%d waves/SIMD=%d : memtime %6.2f ticks/instr/wave (%5.2f per SIMD) ; in-kernel %.3f ms (realtime@100MHz) wall %.3f ms ; memtime rate %.3f GHz ; %.3f ns per instr per SIMD\n", name, ILP,
+         waves_per_simd, mean / n, mean / n / waves_per_simd, mrt / 1e5, ms, mean / (mrt * 10.0), mrt * 10.0 / n / waves_per_simd);
+  (void)hipFree(out);
+  (void)hipFree(cyc);
+  (void)hipFree(rt);
+  return 0;
+}
+
+int main() {
+  for (int w : {1, 2, 4, 8}) { run<0, 1>("v_fma_f64", w); run<0, 4>("v_fma_f64", w); }
+  for (int w : {1, 4}) {
+    run<1, 4>("v_mul_f64", w);
+    run<3, 4>("v_rcp_f64", w);
+    run<4, 4>("v_ldexp_f64", w);
+    run<7, 4>("v_mov_b64", w);
+    run<8, 4>("v_fma_f32", w);
+    run<11, 4>("v_cndmask_b32", w);
+    run<10, 4>("nop+fma_f64", w);
+  }
+  return 0;
+}
