@@ -46,9 +46,10 @@ def allgather_pool(local, group=None):
 
     world = dist.get_world_size(group)
     local = local.contiguous()
-    out = torch.empty((world,) + tuple(local.shape), dtype=local.dtype, device=local.device)
+    # concatenated-along-dim-0 output: the one layout both RCCL and gloo accept
+    out = torch.empty((world * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
     dist.all_gather_into_tensor(out, local, group=group)
-    return out
+    return out.view((world,) + tuple(local.shape))
 
 
 def pool_to_chain_major(pool):

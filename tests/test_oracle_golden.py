@@ -1,0 +1,176 @@
+"""
+CPU tests: the oracle (oracle/rsf_oracle.c and its NumPy/SciPy twin) against the golden vectors
+captured from the live reference by oracle/make_golden.py.  No GPU involved.
+"""
+import numpy as np
+import pytest
+
+
+def _traj_err(a, b):
+    return (np.abs(a - b).max(axis=0) / np.abs(b).max(axis=0)).max()
+
+
+def test_philox_known_answers(cpu_engine):
+    # Random123 kat_vectors, philox4x32-10
+    e = cpu_engine
+    assert e.philox([0, 0, 0, 0], [0, 0]) == [0x6627E8D5, 0xE169C58D, 0xBC57AC4C, 0x9B00DBD8]
+    assert e.philox([0xFFFFFFFF] * 4, [0xFFFFFFFF] * 2) == [0x408F276D, 0x41C83B0E, 0xA20BC7C6, 0x6D5451FD]
+    assert e.philox([0x243F6A88, 0x85A308D3, 0x13198A2E, 0x03707344], [0xA4093822, 0x299F31D0]) == \
+        [0xD16CFE09, 0x94FDCCEB, 0x5001E420, 0x24126EA1]
+
+
+def test_variate_distributions(cpu_engine):
+    """Box-Muller normals, (0,1] uniforms and Marsaglia-Tsang gammas have the right moments."""
+    n, shape = 40000, 250.005
+    z, u, g = np.empty(n), np.empty(n), np.empty(n)
+    for i in range(n):
+        zz, u[i], g[i] = cpu_engine.draws(99, i, 7, 1, shape)
+        z[i] = zz[0]
+    assert abs(z.mean()) < 4 / np.sqrt(n) and abs(z.var() - 1) < 0.03
+    assert abs((z ** 4).mean() - 3) < 0.15
+    assert 0 < u.min() and u.max() <= 1 and abs(u.mean() - 0.5) < 4 / np.sqrt(12 * n)
+    assert abs(g.mean() - shape) < 4 * np.sqrt(shape / n) and abs(g.var() / shape - 1) < 0.05
+    # distinct (chain, iteration) pairs give distinct streams; same pair is reproducible
+    assert cpu_engine.draws(1, 5, 6, 3, shape) == cpu_engine.draws(1, 5, 6, 3, shape)
+    assert cpu_engine.draws(1, 5, 6, 3, shape) != cpu_engine.draws(1, 6, 5, 3, shape)
+
+
+def test_dop853_twin_reproduces_reference_forward(oracle_mod, golden):
+    """The SciPy twin uses the reference's own integrator: it must reproduce evaluate()[1] to rounding."""
+    g, meta = golden.npz("forward"), golden.json("forward")
+    for case in meta["cases"]:
+        if case["nsteps"] != 500 or case["dc"] < 100:
+            continue
+        m = oracle_mod.ModelSpec(case["nsteps"])
+        m.RadiationDamping, m.a, m.b = case["damping"], case["a"], case["b"]
+        acc = oracle_mod.forward_dop853(m, case["dc"])
+        ref = g[case["tag"]]
+        assert len(acc) == case["nout"]
+        assert np.abs(acc - ref).max() <= 1e-11 * np.abs(ref).max(), case["tag"]
+
+
+def test_rk4_converges_to_reference_at_fourth_order(cpu_engine, oracle_mod, golden):
+    """Tier 2: RK4 with S substeps vs the reference's dop853 trajectory."""
+    g = golden.npz("forward")
+    table = {500: {1: 3.6e-4, 2: 2.2e-5, 4: 1.4e-6, 8: 8.4e-8}, 2000: {1: 1.4e-6, 2: 8.5e-8, 4: 5.3e-9}}
+    for n, ladder in table.items():
+        ref = np.stack([g[f"n{n}_dc{dc:g}"] for dc in (100.0, 1000.0, 5000.0)], axis=1)
+        prev = None
+        for S, bound in ladder.items():
+            cpu_engine.set_model(oracle_mod.ModelSpec(n, substeps=S), S)
+            _, acc = cpu_engine.forward([100.0, 1000.0, 5000.0])
+            err = _traj_err(acc, ref)
+            assert err <= 2 * bound, (n, S, err)
+            if prev is not None and err > 5e-9:
+                assert 12 <= prev / err <= 20, (n, S, prev / err)
+            prev = err
+
+
+def test_rk4_forward_other_golden_cases(cpu_engine, oracle_mod, golden):
+    """No-damping and (a, b) variants (pins the 3-parameter forward model), S = 8."""
+    g, meta = golden.npz("forward"), golden.json("forward")
+    for case in meta["cases"]:
+        if case["nsteps"] != 500 or case["dc"] < 100:
+            continue
+        m = oracle_mod.ModelSpec(500, substeps=8)
+        m.RadiationDamping, m.a, m.b = case["damping"], case["a"], case["b"]
+        cpu_engine.set_model(m, 8)
+        _, acc = cpu_engine.forward([case["dc"]])
+        assert _traj_err(acc, g[case["tag"]][:, None]) < 5e-7, case["tag"]
+
+
+def test_c_oracle_matches_numpy_twin(cpu_engine, oracle_mod):
+    m = oracle_mod.ModelSpec(500, substeps=2)
+    cpu_engine.set_model(m, 2)
+    dc = np.array([80.0, 1000.0, 7000.0])
+    a, b = np.array([0.011, 0.013, 0.009]), np.array([0.014, 0.012, 0.02])
+    _, acc = cpu_engine.forward(dc, a=a, b=b)
+    twin = oracle_mod.forward_rk4(m, dc, a, b)
+    assert _traj_err(acc, twin) < 1e-11
+    data = twin[:, 1] * 1.01
+    ssq, _ = cpu_engine.forward(dc, a=a, b=b, data=data, want_ssq=True, want_acc=False)
+    np.testing.assert_allclose(ssq, oracle_mod.ssq_rk4(m, dc, data, a, b), rtol=1e-10)
+
+
+def test_ssq_grid_against_reference(cpu_engine, oracle_mod, golden):
+    g = golden.npz("ssq")
+    big = g["qgrid"] >= 700.0  # the S = 1 ladder value (7.4e-5) is for Dc >~ 100-1000; smaller Dc is stiffer
+    for S, tol_big, tol_small in ((1, 1e-3, 2e-3), (8, 3e-7, 1e-6)):
+        cpu_engine.set_model(oracle_mod.ModelSpec(500, substeps=S), S)
+        ssq, _ = cpu_engine.forward(g["qgrid"], data=g["data"], want_ssq=True, want_acc=False)
+        np.testing.assert_allclose(ssq[big], g["ssq"][big], rtol=tol_big)
+        np.testing.assert_allclose(ssq[~big], g["ssq"][~big], rtol=tol_small)
+
+
+def test_initial_covariance_against_reference(cpu_engine, oracle_mod, golden):
+    """std2[0] with the len(qpriors) divisor quirk (3 list / 2 dict) and Vstart (MCMC.py:244-266)."""
+    g, cases = golden.npz("ssq"), golden.json("init")["cases"]
+    cpu_engine.set_model(oracle_mod.ModelSpec(500, substeps=8), 8)
+    for name, c in cases.items():
+        cpu_engine.mcmc_init([[c["qstart"]]], g["data"], [0.0], [1e4], prior_len=c["prior_len"])
+        _, _, std2, V = cpu_engine.get_state()
+        np.testing.assert_allclose(std2[0], c["std2_0"], rtol=1e-6, err_msg=name)
+        # Vstart is a forward difference with relative step 1e-6 of trajectories that dop853 only resolves to
+        # ~1e-10: the reference's own value carries ~1e-4 of integrator noise
+        np.testing.assert_allclose(V[0, 0, 0], c["vstart"], rtol=5e-3, err_msg=name)
+
+
+@pytest.mark.parametrize("tag", ["list", "dict", "tightbox"])
+def test_sampler_logic_replays_reference_exactly(oracle_mod, golden, tag):
+    """Feeding the recorded variates AND the recorded SSq values through the restated sampler logic must
+    give the reference's chain bit-for-bit (accept rule, sigma^2 update, adaptation quirks)."""
+    g, meta = golden.npz("replay_" + tag), golden.json("replay_" + tag)
+    prior = meta["prior"] if isinstance(meta["prior"], list) else {int(k): v for k, v in meta["prior"].items()}
+    s = oracle_mod.ReferenceSampler(None, meta["nsteps"], prior, meta["qstart"], n0=meta["n0"], adapt_interval=meta["adapt_interval"])
+    s.set_initial(meta["std2_0"], meta["vstart"], meta["ssq0"])
+    n = len(g["z"])
+    for i in range(n):
+        assert s.V == pytest.approx(g["vold"][i], rel=1e-14)
+        inb, acc, q_new = s.step(i, g["z"][i], g["u"][i], g["g"][i], ssq_new=g["ssq_new"][i])
+        assert inb == bool(g["inb"][i])
+        assert q_new == pytest.approx(g["q_prop"][i], rel=1e-14)
+        assert s.ssq == pytest.approx(g["ssq_after"][i], rel=1e-14)
+        assert s.std2[-1] == pytest.approx(g["std2_after"][i], rel=1e-13)
+    nb = meta["nburn"]
+    np.testing.assert_allclose(s.qparams[nb:], g["qparams_kept"][0], rtol=1e-14)
+    np.testing.assert_allclose(s.std2[nb:], g["std2_kept"], rtol=1e-13)
+    if tag == "tightbox":
+        assert (g["inb"] == 0).sum() > 5  # the fixture really exercises out-of-bounds proposals
+    if tag == "dict":
+        assert len(set(np.round(g["vold"], 6))) > 3  # and the dict prior really adapts
+
+
+@pytest.mark.parametrize("tag", ["list", "dict", "tightbox"])
+def test_c_oracle_replays_reference_chain(cpu_engine, oracle_mod, golden, tag):
+    """C restatement with its own RK4 (S = 8) forward model, driven by the reference's variates."""
+    g, meta = golden.npz("replay_" + tag), golden.json("replay_" + tag)
+    is_list = isinstance(meta["prior"], list)
+    lo, hi = (meta["prior"][1], meta["prior"][2]) if is_list else (meta["prior"]["1"], meta["prior"]["2"])
+    cpu_engine.set_model(oracle_mod.ModelSpec(meta["nsteps"], substeps=8), 8)
+    cpu_engine.mcmc_init([[meta["qstart"]]], g["data"], [lo], [hi], prior_len=3 if is_list else 2,
+                         adapt_mode="none" if is_list else "reference_dict", adapt_interval=meta["adapt_interval"])
+    _, ssq, std2, _ = cpu_engine.get_state()
+    np.testing.assert_allclose([ssq[0], std2[0]], [meta["ssq0"], meta["std2_0"]], rtol=1e-6)
+    cpu_engine.set_state(V=[[[meta["vstart"]]]], std2=[meta["std2_0"]], ssq=[meta["ssq0"]])
+    n = len(g["z"])
+    u = np.where(np.isnan(g["u"]), 1.0, g["u"])
+    tq, ts, ta = cpu_engine.mcmc_replay(g["z"].reshape(n, 1, 1), u.reshape(n, 1), g["g"].reshape(n, 1))
+    nb = meta["nburn"]
+    np.testing.assert_allclose(tq[nb - 1:, 0, 0], g["qparams_kept"][0], rtol=1e-6)
+    np.testing.assert_allclose(ts[nb - 1:, 0], g["std2_kept"], rtol=1e-5)
+    assert cpu_engine.stats()["evaluated"] == int(g["inb"].sum())
+
+
+def test_mcmc_statistical_sanity(cpu_engine, oracle_mod):
+    """Pooled posterior of many short chains is centred on the truth (Tier 3 flavour, small)."""
+    from conftest import synthetic_data
+
+    cpu_engine.set_model(oracle_mod.ModelSpec(500), 1)
+    data = synthetic_data(cpu_engine)
+    cpu_engine.mcmc_init(np.full((64, 1), 1000.0), data, [0.0], [1e4], seed=2025, prior_len=3)
+    tq, ts, ta = cpu_engine.mcmc_run(120)
+    kept = tq[60:, :, 0]
+    assert abs(kept.mean() - 1000.0) < 60.0 and 15.0 < kept.std() < 120.0
+    assert 0.4 < ta.mean() < 0.95
+    st = cpu_engine.stats()
+    assert st["evaluated"] == 64 * 120 and st["nonfinite"] == 0 and st["iters_done"] == 120
