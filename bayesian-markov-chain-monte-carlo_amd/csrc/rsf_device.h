@@ -63,9 +63,11 @@ __device__ __forceinline__ Lane make_lane(double dc, double a, double b, const C
 // Same quantities as the reference, regrouped so that every reciprocal is hoisted into Lane and
 // the slip rate appears only as w = v/V_ref = exp((mu-mu_ref)/a - (b/a) log(V_ref*theta/Dc)).
 // ---------------------------------------------------------------------------------------------
-struct Base {   // transcendental results at the start point of the RK4 step (stage 1)
-  double w;     // v/V_ref
-  double rth;   // 1/theta
+// Integration state of one lane.  (w, rth) are the transcendental parts of the RHS at (mu, th):
+//   w = v/V_ref = exp((mu-mu_ref)/a - (b/a) log(V_ref*th/Dc)),   rth = 1/th.
+struct State {
+  double mu, th, V;
+  double w, rth;
 };
 
 // the part of the RHS after w = v/V_ref and 1/theta are known
@@ -83,58 +85,24 @@ __device__ __forceinline__ void rhs_tail(double w, double rth, double th, double
   }
 }
 
-// w = v/V_ref and 1/theta by full evaluation
-__device__ __forceinline__ void rhs_full(double mu, double th, const Lane &L, Base &B) {
+// (w, 1/theta) by full evaluation
+__device__ __forceinline__ void eval_full(double mu, double th, const Lane &L, double &w, double &rth) {
 #ifdef RSF_MATH_OCML
-  B.w = ::exp(__builtin_fma(-L.boa, ::log(th * L.xs), __builtin_fma(mu, L.inv_a, L.tc)));
-  B.rth = 1.0 / th;
+  w = ::exp(__builtin_fma(-L.boa, ::log(th * L.xs), __builtin_fma(mu, L.inv_a, L.tc)));
+  rth = 1.0 / th;
 #else
-  B.w = fm::exp(__builtin_fma(-L.boa, fm::log(th * L.xs), __builtin_fma(mu, L.inv_a, L.tc)));
-  B.rth = fm::rcp(th);
+  w = fm::exp(__builtin_fma(-L.boa, fm::log(th * L.xs), __builtin_fma(mu, L.inv_a, L.tc)));
+  rth = fm::rcp(th);
 #endif
 }
 
-// One classical RK4 step of size h; vl0/vlm/vl1 = V_l at t, t+h/2, t+h.
-//
-// Stage 1 evaluates log / exp / reciprocal in full and keeps the results B at (mu, th).  Stages
-// 2-4 are at (mu + dmu, th + dth) with small increments, so with rho = dth/th and
-// dlt = dmu/a - (b/a) log1p(rho):
-//     w' = w * exp(dlt),     1/th' = (1/th) / (1 + rho),
-// evaluated by short series — the same function of (mu', th') to rounding as long as |rho| and
-// |dmu/a| stay below 2^-8 (truncation < 1e-17), which holds for the step sizes and Dc range the
-// sampler visits.  The code is straight-line (a lone wave per SIMD pays ~9 cycles per dependent
-// fp64 op and a full issue slot per branch/nop, measured with tools/microbench_fp64.hip): the
-// largest increment of the step is tracked with v_max_f64 and checked ONCE per step; if any
-// lane exceeded the bound the step is redone with full evaluations (rk4_step_full, cold path).
-template <bool DAMP>
-__device__ __forceinline__ void rk4_step_full(double &mu, double &th, double &V, double vl0, double vlm,
-                                                        double vl1, const Lane &L, const Consts &K) {
-  double k0 = 0.0, k1 = 0.0, s0 = 0.0, s1 = 0.0, s2 = 0.0;
-#pragma nounroll
-  for (int s = 0; s < 4; ++s) {
-    const double c = s == 0 ? 0.0 : (s == 3 ? K.h : K.hh);
-    const double wgt = (s == 0 || s == 3) ? 1.0 : 2.0;
-    const double vl = s == 0 ? vl0 : (s == 3 ? vl1 : vlm);
-    const double th1 = __builtin_fma(c, k1, th);
-    Base F;
-    rhs_full(__builtin_fma(c, k0, mu), th1, L, F);
-    double d0, d1, d2;
-    rhs_tail<DAMP>(F.w, F.rth, th1, vl, L, K, d0, d1, d2);
-    s0 = __builtin_fma(wgt, d0, s0);
-    s1 = __builtin_fma(wgt, d1, s1);
-    s2 = __builtin_fma(wgt, d2, s2);
-    k0 = d0;
-    k1 = d1;
-  }
-  mu = __builtin_fma(K.h6, s0, mu);
-  th = __builtin_fma(K.h6, s1, th);
-  V = __builtin_fma(K.h6, s2, V);
-}
-
-// incremental stage: (w, 1/th) at (mu + dmu, th + dth) from B at (mu, th); updates the bound tracker
-__device__ __forceinline__ void incr_eval(double dmu, double dth, double th1, const Lane &L, const Base &B,
+// (w', 1/th') at (mu + dmu, th1 = th + dth) from (w, rth) at (mu, th).  With rho = dth/th and
+// dlt = dmu/a - (b/a) log1p(rho):   w' = w exp(dlt),   1/th' = (1/th)/(1 + rho),
+// by short series — the same function of (mu', th') to rounding while |rho|, |dmu/a| < 2^-8
+// (truncation < 1e-17).  `big` tracks the largest increment seen.
+__device__ __forceinline__ void eval_incr(double dmu, double dth, double th1, const Lane &L, double w0, double rth0,
                                           double &w, double &rth, double &big) {
-  const double rho = dth * B.rth;
+  const double rho = dth * rth0;
   const double dm = dmu * L.inv_a;
   big = __builtin_fmax(big, __builtin_fmax(__builtin_fabs(rho), __builtin_fabs(dm)));
   // log1p(rho) = rho - rho^2/2 + ... - rho^6/6              (next term < 2^-56/7)
@@ -153,57 +121,110 @@ __device__ __forceinline__ void incr_eval(double dmu, double dth, double th1, co
   e = fm::hfma(e, dlt, 1.0 / 6.0);
   e = __builtin_fma(e, dlt, 0.5);
   e = __builtin_fma(e, dlt, 1.0);
-  w = __builtin_fma(B.w, e * dlt, B.w);
+  w = __builtin_fma(w0, e * dlt, w0);
   // 1/th' from 1/th: first-order start (error rho^2 < 2^-16), two Newton steps (-> 2^-64)
-  rth = __builtin_fma(-rho, B.rth, B.rth);
+  rth = __builtin_fma(-rho, rth0, rth0);
   double r = __builtin_fma(-th1, rth, 1.0);
   rth = __builtin_fma(rth, r, rth);
   r = __builtin_fma(-th1, rth, 1.0);
   rth = __builtin_fma(rth, r, rth);
 }
 
-template <bool DAMP>
-__device__ __forceinline__ void rk4_step(double &mu, double &th, double &V, double vl0, double vlm,
-                                         double vl1, const Lane &L, const Consts &K) {
-#ifdef RSF_NO_INCREMENTAL
-  double a0, a1, a2, b0, b1, b2, c0, c1, c2, e0, e1, e2;
-  Base F;
-  rhs_full(mu, th, L, F);
-  rhs_tail<DAMP>(F.w, F.rth, th, vl0, L, K, a0, a1, a2);
-  double t = __builtin_fma(K.hh, a1, th);
-  rhs_full(__builtin_fma(K.hh, a0, mu), t, L, F);
-  rhs_tail<DAMP>(F.w, F.rth, t, vlm, L, K, b0, b1, b2);
-  t = __builtin_fma(K.hh, b1, th);
-  rhs_full(__builtin_fma(K.hh, b0, mu), t, L, F);
-  rhs_tail<DAMP>(F.w, F.rth, t, vlm, L, K, c0, c1, c2);
-  t = __builtin_fma(K.h, c1, th);
-  rhs_full(__builtin_fma(K.h, c0, mu), t, L, F);
-  rhs_tail<DAMP>(F.w, F.rth, t, vl1, L, K, e0, e1, e2);
-  mu = mu + K.h6 * (a0 + 2.0 * b0 + 2.0 * c0 + e0);
-  th = th + K.h6 * (a1 + 2.0 * b1 + 2.0 * c1 + e1);
-  V = V + K.h6 * (a2 + 2.0 * b2 + 2.0 * c2 + e2);
-#else
-  double a0, a1, a2, b0, b1, b2, c0, c1, c2, e0, e1, e2, w, rth, big = 0.0;
-  Base B;
-  rhs_full(mu, th, L, B);
-  rhs_tail<DAMP>(B.w, B.rth, th, vl0, L, K, a0, a1, a2);
-  double dth = K.hh * a1;
-  incr_eval(K.hh * a0, dth, th + dth, L, B, w, rth, big);
-  rhs_tail<DAMP>(w, rth, th + dth, vlm, L, K, b0, b1, b2);
-  dth = K.hh * b1;
-  incr_eval(K.hh * b0, dth, th + dth, L, B, w, rth, big);
-  rhs_tail<DAMP>(w, rth, th + dth, vlm, L, K, c0, c1, c2);
-  dth = K.h * c1;
-  incr_eval(K.h * c0, dth, th + dth, L, B, w, rth, big);
-  rhs_tail<DAMP>(w, rth, th + dth, vl1, L, K, e0, e1, e2);
-  if (__builtin_expect(!(big < 0x1.0p-8), 0)) {   // some increment too large (or Inf): cold path, NaN passes through
-    rk4_step_full<DAMP>(mu, th, V, vl0, vlm, vl1, L, K);
-    return;
-  }
-  mu = mu + K.h6 * (a0 + 2.0 * b0 + 2.0 * c0 + e0);
-  th = th + K.h6 * (a1 + 2.0 * b1 + 2.0 * c1 + e1);
-  V = V + K.h6 * (a2 + 2.0 * b2 + 2.0 * c2 + e2);
+// ---------------------------------------------------------------------------------------------
+// One classical RK4 step of size h; vl0/vlm/vl1 = V_l at t, t+h/2, t+h.
+//
+// Hot path (rk4_fast): the state carries (w, 1/th) at its own point, so stage 1 needs no
+// transcendental at all; stages 2-4 and the step's end point are reached by eval_incr from the
+// step's start point.  Straight-line code on purpose: with one wave per SIMD (cfg1) every
+// instruction, nop and branch costs a full ~5-cycle issue slot (tools/microbench_fp64.hip).
+// The largest relative increment of the step is checked ONCE; if a lane exceeded 2^-8 (stiff
+// small-Dc proposals) the step is redone from the saved start point with full evaluations
+// (rk4_cold).  Every RSF_RESYNC steps (w, 1/th) are recomputed in full so rounding in the
+// incremental products cannot accumulate (1/th is self-correcting through its Newton steps).
+// ---------------------------------------------------------------------------------------------
+#ifndef RSF_RESYNC
+#define RSF_RESYNC 32
 #endif
+
+template <bool DAMP>
+__device__ __forceinline__ void rk4_cold(State &s, double vl0, double vlm, double vl1, const Lane &L,
+                                         const Consts &K) {
+  double k0 = 0.0, k1 = 0.0, s0 = 0.0, s1 = 0.0, s2 = 0.0;
+#pragma nounroll
+  for (int st = 0; st < 4; ++st) {
+    const double c = st == 0 ? 0.0 : (st == 3 ? K.h : K.hh);
+    const double wgt = (st == 0 || st == 3) ? 1.0 : 2.0;
+    const double vl = st == 0 ? vl0 : (st == 3 ? vl1 : vlm);
+    const double th1 = __builtin_fma(c, k1, s.th);
+    double w, rth, d0, d1, d2;
+    eval_full(__builtin_fma(c, k0, s.mu), th1, L, w, rth);
+    rhs_tail<DAMP>(w, rth, th1, vl, L, K, d0, d1, d2);
+    s0 = __builtin_fma(wgt, d0, s0);
+    s1 = __builtin_fma(wgt, d1, s1);
+    s2 = __builtin_fma(wgt, d2, s2);
+    k0 = d0;
+    k1 = d1;
+  }
+  s.mu = __builtin_fma(K.h6, s0, s.mu);
+  s.th = __builtin_fma(K.h6, s1, s.th);
+  s.V = __builtin_fma(K.h6, s2, s.V);
+  eval_full(s.mu, s.th, L, s.w, s.rth);
+}
+
+template <bool DAMP>
+__device__ __forceinline__ void rk4_fast(State &s, double vl0, double vlm, double vl1, const Lane &L,
+                                         const Consts &K, double &big) {
+  double a0, a1, a2, b0, b1, b2, c0, c1, c2, e0, e1, e2, w, rth;
+  rhs_tail<DAMP>(s.w, s.rth, s.th, vl0, L, K, a0, a1, a2);
+  double dth = K.hh * a1;
+  eval_incr(K.hh * a0, dth, s.th + dth, L, s.w, s.rth, w, rth, big);
+  rhs_tail<DAMP>(w, rth, s.th + dth, vlm, L, K, b0, b1, b2);
+  dth = K.hh * b1;
+  eval_incr(K.hh * b0, dth, s.th + dth, L, s.w, s.rth, w, rth, big);
+  rhs_tail<DAMP>(w, rth, s.th + dth, vlm, L, K, c0, c1, c2);
+  dth = K.h * c1;
+  eval_incr(K.h * c0, dth, s.th + dth, L, s.w, s.rth, w, rth, big);
+  rhs_tail<DAMP>(w, rth, s.th + dth, vl1, L, K, e0, e1, e2);
+  const double dmu = K.h6 * (a0 + 2.0 * b0 + 2.0 * c0 + e0);
+  dth = K.h6 * (a1 + 2.0 * b1 + 2.0 * c1 + e1);
+  const double th1 = s.th + dth;
+  eval_incr(dmu, dth, th1, L, s.w, s.rth, w, rth, big);
+  s.mu = s.mu + dmu;
+  s.th = th1;
+  s.V = s.V + K.h6 * (a2 + 2.0 * b2 + 2.0 * c2 + e2);
+  s.w = w;
+  s.rth = rth;
+}
+
+// advance one step; `rs` counts steps until the next full re-evaluation of (w, 1/th) (wave-uniform)
+template <bool DAMP>
+__device__ __forceinline__ void rk4_step(State &s, int &rs, double vl0, double vlm, double vl1, const Lane &L,
+                                         const Consts &K) {
+#ifdef RSF_NO_INCREMENTAL
+  rk4_cold<DAMP>(s, vl0, vlm, vl1, L, K);
+#else
+  if (rs == 0) {
+    eval_full(s.mu, s.th, L, s.w, s.rth);
+    rs = RSF_RESYNC;
+  }
+  --rs;
+  const State save = s;
+  double big = 0.0;
+  rk4_fast<DAMP>(s, vl0, vlm, vl1, L, K, big);
+  if (__builtin_expect(!(big < 0x1.0p-8), 0)) {  // an increment too large (or Inf; NaN passes through): cold path
+    s = save;
+    rk4_cold<DAMP>(s, vl0, vlm, vl1, L, K);
+  }
+#endif
+}
+
+__device__ __forceinline__ State initial_state(double dc, const Lane &L, const Consts &K) {
+  State s;
+  s.mu = K.mu0;                 // RateStateModel.py:367-377
+  s.th = dc / K.V_ref;
+  s.V = K.V_ref;
+  eval_full(s.mu, s.th, L, s.w, s.rth);
+  return s;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -229,14 +250,14 @@ __device__ __forceinline__ void stage_chunk(double *lds, const Consts &K, int k0
 // (MCMC.py:387) and optionally stores acc time-major.  Called under the lane's activity mask.
 template <bool DAMP, bool WANT_SSQ, bool WANT_ACC>
 __device__ __forceinline__ void integrate_chunk(const double *lds, const Consts &K, const Lane &L, int k0,
-                                                int kn, double &mu, double &th, double &V, double &ssq,
-                                                double *acc_out, int64_t stride) {
+                                                int kn, State &s, int &rs, double &ssq, double *acc_out,
+                                                int64_t stride) {
   const double *ld = lds + lds_data_offset(K);
   int j = 0;
   for (int kk = 0; kk < kn; ++kk) {
-    const double vprev = V;
-    for (int s = 0; s < K.S; ++s, j += 2) rk4_step<DAMP>(mu, th, V, lds[j], lds[j + 1], lds[j + 2], L, K);
-    const double ak = (V - vprev) * K.inv_dt;  // RateStateModel.py:388
+    const double vprev = s.V;
+    for (int sub = 0; sub < K.S; ++sub, j += 2) rk4_step<DAMP>(s, rs, lds[j], lds[j + 1], lds[j + 2], L, K);
+    const double ak = (s.V - vprev) * K.inv_dt;  // RateStateModel.py:388
     if (WANT_ACC) acc_out[(int64_t)(k0 + kk) * stride] = ak;
     if (WANT_SSQ) {
       const double r = ak - ld[kk];
@@ -251,7 +272,8 @@ template <bool DAMP, bool WANT_SSQ, bool WANT_ACC, bool RESIDENT>
 __device__ __forceinline__ double solve(double *lds, const Consts &K, bool active, double dc, double a,
                                         double b, double *acc_out, int64_t stride) {
   const Lane L = make_lane(dc, a, b, K);
-  double mu = K.mu0, th = dc / K.V_ref, V = K.V_ref;  // RateStateModel.py:367-377
+  State s = initial_state(dc, L, K);
+  int rs = RSF_RESYNC;
   double ssq = 0.0;
   if (WANT_SSQ && active) {
     const double d0 = K.data[0];  // sample 0 belongs to no chunk: acc[0] = 0, RateStateModel.py:371
@@ -259,12 +281,12 @@ __device__ __forceinline__ double solve(double *lds, const Consts &K, bool activ
   }
   if (WANT_ACC && active) acc_out[0] = 0.0;
   if (RESIDENT) {
-    if (active) integrate_chunk<DAMP, WANT_SSQ, WANT_ACC>(lds, K, L, 1, K.nout - 1, mu, th, V, ssq, acc_out, stride);
+    if (active) integrate_chunk<DAMP, WANT_SSQ, WANT_ACC>(lds, K, L, 1, K.nout - 1, s, rs, ssq, acc_out, stride);
   } else {
     for (int k0 = 1; k0 < K.nout; k0 += K.kc) {
       const int kn = min(K.kc, K.nout - k0);
       stage_chunk(lds, K, k0, kn);
-      if (active) integrate_chunk<DAMP, WANT_SSQ, WANT_ACC>(lds, K, L, k0, kn, mu, th, V, ssq, acc_out, stride);
+      if (active) integrate_chunk<DAMP, WANT_SSQ, WANT_ACC>(lds, K, L, k0, kn, s, rs, ssq, acc_out, stride);
     }
   }
   return ssq;

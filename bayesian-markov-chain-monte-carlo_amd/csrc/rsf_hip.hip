@@ -92,16 +92,20 @@ __global__ void __launch_bounds__(kMaxBlock) init_kernel(Consts K, InitArgs A) {
     if (D == 3) { p0[1] = A.q0[i * D + 1]; p0[2] = A.q0[i * D + 2]; }
   }
   rsf::Lane L[D + 1];
-  double mu[D + 1], th[D + 1], V[D + 1], inv_den[D];
+  rsf::State st[D + 1];
+  int rs[D + 1];
+  double inv_den[D];
   L[0] = rsf::make_lane(p0[0], p0[1], p0[2], K);
-  mu[0] = K.mu0; th[0] = p0[0] / K.V_ref; V[0] = K.V_ref;
+  st[0] = rsf::initial_state(p0[0], L[0], K);
+  rs[0] = RSF_RESYNC;
 #pragma unroll
   for (int p = 0; p < D; ++p) {
     double pq[3] = {p0[0], p0[1], p0[2]};
     pq[p] = pq[p] * (1 + A.fd);
     inv_den[p] = 1.0 / (pq[p] * A.fd);  // perturbed value in the denominator, MCMC.py:264
     L[p + 1] = rsf::make_lane(pq[0], pq[1], pq[2], K);
-    mu[p + 1] = K.mu0; th[p + 1] = pq[0] / K.V_ref; V[p + 1] = K.V_ref;
+    st[p + 1] = rsf::initial_state(pq[0], L[p + 1], K);
+    rs[p + 1] = RSF_RESYNC;
   }
   double xtx[D * D];
 #pragma unroll
@@ -117,13 +121,13 @@ __global__ void __launch_bounds__(kMaxBlock) init_kernel(Consts K, InitArgs A) {
     for (int kk = 0; kk < kn; ++kk) {
       double ak[D + 1];
 #pragma unroll
-      for (int t = 0; t <= D; ++t) ak[t] = V[t];
+      for (int t = 0; t <= D; ++t) ak[t] = st[t].V;
       for (int s = 0; s < K.S; ++s, j += 2) {
 #pragma unroll
-        for (int t = 0; t <= D; ++t) rsf::rk4_step<DAMP>(mu[t], th[t], V[t], lds[j], lds[j + 1], lds[j + 2], L[t], K);
+        for (int t = 0; t <= D; ++t) rsf::rk4_step<DAMP>(st[t], rs[t], lds[j], lds[j + 1], lds[j + 2], L[t], K);
       }
 #pragma unroll
-      for (int t = 0; t <= D; ++t) ak[t] = (V[t] - ak[t]) * K.inv_dt;
+      for (int t = 0; t <= D; ++t) ak[t] = (st[t].V - ak[t]) * K.inv_dt;
       const double r = ak[0] - ld[kk];
       ssq += r * r;
       double x[D];
