@@ -1,0 +1,72 @@
+#!/usr/bin/env python3
+"""Summarise the rocprofv3 passes written by tools/profile_gpu.sh into profiles/<round>/ (tracked).
+
+  python tools/summarize_profile.py gpurun_out/prof_cfg1 cfg1 profiles/r01 [build-tag]
+
+Writes <tag>_<build>_kernel_stats.csv (copy of rocprofv3 --stats), <tag>_<build>_pmc.json (per-launch
+averages of the dominant kernel's counters, HBM traffic with the gfx950 FETCH_SIZE correction from
+MI355X_MICROARCH.md §HBM) and updates profiles/pmc_traffic.json, which bench.py reports as
+roofline.traffic."""
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+from collections import defaultdict
+
+
+def rows(pattern):
+    out = []
+    for f in glob.glob(pattern, recursive=True):
+        out += list(csv.DictReader(open(f)))
+    return out
+
+
+def main():
+    src, tag, dst = sys.argv[1:4]
+    build = sys.argv[4] if len(sys.argv) > 4 else "latest"
+    os.makedirs(dst, exist_ok=True)
+    stats = glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True)[0]
+    shutil.copy(stats, os.path.join(dst, f"{tag}_{build}_kernel_stats.csv"))
+    top = max(csv.DictReader(open(stats)), key=lambda r: float(r["TotalDurationNs"]))
+    kern = top["Name"]
+    summary = {"kernel": kern, "calls": int(top["Calls"]), "avg_ms": float(top["AverageNs"]) / 1e6,
+               "share_of_gpu_time_pct": float(top["Percentage"])}
+    trace = [r for r in rows(os.path.join(src, "trace", "**", "*kernel_trace.csv")) if r["Kernel_Name"] == kern]
+    if trace:
+        t = trace[-1]
+        summary.update(vgpr=int(t["VGPR_Count"]), sgpr=int(t["SGPR_Count"]), lds_bytes=int(t["LDS_Block_Size"]),
+                       scratch=int(t["Scratch_Size"]), workgroup=int(t["Workgroup_Size_X"]), grid=int(t["Grid_Size_X"]))
+    counters = defaultdict(list)
+    for p in ("pmc_sq", "pmc_fetch", "pmc_write"):
+        per_dispatch = defaultdict(float)
+        for r in rows(os.path.join(src, p, "**", "*counter_collection.csv")):
+            if r["Kernel_Name"] == kern:
+                per_dispatch[(r["Dispatch_Id"], r["Counter_Name"])] += float(r["Counter_Value"])
+        for (_, name), v in per_dispatch.items():
+            counters[name].append(v)
+    pmc = {k: sum(v) / len(v) for k, v in counters.items()}
+    summary["pmc_per_launch"] = pmc
+    if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
+        # rocprofv3 reports KiB; on gfx950 FETCH_SIZE counts 64 B per 128-B read request for wide coalesced
+        # streams (MI355X_MICROARCH.md §HBM): doubled bytes are the upper estimate, raw the lower.
+        fetch_lo, write = pmc["FETCH_SIZE"] * 1024, pmc["WRITE_SIZE"] * 1024
+        summary["hbm_bytes_per_launch"] = {"fetch_raw": fetch_lo, "fetch_corrected_x2": 2 * fetch_lo, "write": write,
+                                           "total_corrected": 2 * fetch_lo + write}
+    if "SQ_INSTS_VALU" in pmc and "SQ_WAVES" in pmc:
+        summary["valu_insts_per_wave"] = pmc["SQ_INSTS_VALU"] / pmc["SQ_WAVES"]
+    if "SQ_ACTIVE_INST_VALU" in pmc and "SQ_BUSY_CYCLES" in pmc:
+        summary["note_units"] = "SQ_* cycle counters are in quad-cycles summed over SEs/XCDs (MI355X_MICROARCH.md)"
+    json.dump(summary, open(os.path.join(dst, f"{tag}_{build}_pmc.json"), "w"), indent=1)
+    tfile = os.path.join(os.path.dirname(dst.rstrip("/")), "pmc_traffic.json")
+    traffic = json.load(open(tfile)) if os.path.exists(tfile) else {}
+    if "hbm_bytes_per_launch" in summary:
+        traffic[tag] = summary["hbm_bytes_per_launch"]["total_corrected"]
+        traffic[tag + "_source"] = f"{dst}/{tag}_{build}_pmc.json"
+        json.dump(traffic, open(tfile, "w"), indent=1)
+    print(json.dumps(summary, indent=1))
+
+
+if __name__ == "__main__":
+    main()
