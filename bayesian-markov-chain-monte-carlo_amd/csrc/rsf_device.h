@@ -196,18 +196,14 @@ __device__ __forceinline__ void rk4_fast(State &s, double vl0, double vlm, doubl
   s.rth = rth;
 }
 
-// advance one step; `rs` counts steps until the next full re-evaluation of (w, 1/th) (wave-uniform)
+// advance one step; `resync` (wave-uniform, from the step index) asks for a full re-evaluation of (w, 1/th) first
 template <bool DAMP>
-__device__ __forceinline__ void rk4_step(State &s, int &rs, double vl0, double vlm, double vl1, const Lane &L,
+__device__ __forceinline__ void rk4_step(State &s, bool resync, double vl0, double vlm, double vl1, const Lane &L,
                                          const Consts &K) {
 #ifdef RSF_NO_INCREMENTAL
   rk4_cold<DAMP>(s, vl0, vlm, vl1, L, K);
 #else
-  if (rs == 0) {
-    eval_full(s.mu, s.th, L, s.w, s.rth);
-    rs = RSF_RESYNC;
-  }
-  --rs;
+  if (resync) eval_full(s.mu, s.th, L, s.w, s.rth);
   const State save = s;
   double big = 0.0;
   rk4_fast<DAMP>(s, vl0, vlm, vl1, L, K, big);
@@ -250,13 +246,27 @@ __device__ __forceinline__ void stage_chunk(double *lds, const Consts &K, int k0
 // (MCMC.py:387) and optionally stores acc time-major.  Called under the lane's activity mask.
 template <bool DAMP, bool WANT_SSQ, bool WANT_ACC>
 __device__ __forceinline__ void integrate_chunk(const double *lds, const Consts &K, const Lane &L, int k0,
-                                                int kn, State &s, int &rs, double &ssq, double *acc_out,
-                                                int64_t stride) {
+                                                int kn, State &s, double &ssq, double *acc_out, int64_t stride) {
   const double *ld = lds + lds_data_offset(K);
+  if (K.S == 1) {  // one step per output sample: flat loop
+    for (int kk = 0; kk < kn; ++kk) {
+      const double vprev = s.V;
+      const int j = 2 * kk;
+      rk4_step<DAMP>(s, (kk & (RSF_RESYNC - 1)) == RSF_RESYNC - 1, lds[j], lds[j + 1], lds[j + 2], L, K);
+      const double ak = (s.V - vprev) * K.inv_dt;  // RateStateModel.py:388
+      if (WANT_ACC) acc_out[(int64_t)(k0 + kk) * stride] = ak;
+      if (WANT_SSQ) {
+        const double r = ak - ld[kk];
+        ssq += r * r;
+      }
+    }
+    return;
+  }
   int j = 0;
   for (int kk = 0; kk < kn; ++kk) {
     const double vprev = s.V;
-    for (int sub = 0; sub < K.S; ++sub, j += 2) rk4_step<DAMP>(s, rs, lds[j], lds[j + 1], lds[j + 2], L, K);
+    for (int sub = 0; sub < K.S; ++sub, j += 2)
+      rk4_step<DAMP>(s, (j & (2 * RSF_RESYNC - 1)) == 2 * RSF_RESYNC - 2, lds[j], lds[j + 1], lds[j + 2], L, K);
     const double ak = (s.V - vprev) * K.inv_dt;  // RateStateModel.py:388
     if (WANT_ACC) acc_out[(int64_t)(k0 + kk) * stride] = ak;
     if (WANT_SSQ) {
@@ -273,7 +283,6 @@ __device__ __forceinline__ double solve(double *lds, const Consts &K, bool activ
                                         double b, double *acc_out, int64_t stride) {
   const Lane L = make_lane(dc, a, b, K);
   State s = initial_state(dc, L, K);
-  int rs = RSF_RESYNC;
   double ssq = 0.0;
   if (WANT_SSQ && active) {
     const double d0 = K.data[0];  // sample 0 belongs to no chunk: acc[0] = 0, RateStateModel.py:371
@@ -281,12 +290,12 @@ __device__ __forceinline__ double solve(double *lds, const Consts &K, bool activ
   }
   if (WANT_ACC && active) acc_out[0] = 0.0;
   if (RESIDENT) {
-    if (active) integrate_chunk<DAMP, WANT_SSQ, WANT_ACC>(lds, K, L, 1, K.nout - 1, s, rs, ssq, acc_out, stride);
+    if (active) integrate_chunk<DAMP, WANT_SSQ, WANT_ACC>(lds, K, L, 1, K.nout - 1, s, ssq, acc_out, stride);
   } else {
     for (int k0 = 1; k0 < K.nout; k0 += K.kc) {
       const int kn = min(K.kc, K.nout - k0);
       stage_chunk(lds, K, k0, kn);
-      if (active) integrate_chunk<DAMP, WANT_SSQ, WANT_ACC>(lds, K, L, k0, kn, s, rs, ssq, acc_out, stride);
+      if (active) integrate_chunk<DAMP, WANT_SSQ, WANT_ACC>(lds, K, L, k0, kn, s, ssq, acc_out, stride);
     }
   }
   return ssq;

@@ -93,11 +93,9 @@ __global__ void __launch_bounds__(kMaxBlock) init_kernel(Consts K, InitArgs A) {
   }
   rsf::Lane L[D + 1];
   rsf::State st[D + 1];
-  int rs[D + 1];
   double inv_den[D];
   L[0] = rsf::make_lane(p0[0], p0[1], p0[2], K);
   st[0] = rsf::initial_state(p0[0], L[0], K);
-  rs[0] = RSF_RESYNC;
 #pragma unroll
   for (int p = 0; p < D; ++p) {
     double pq[3] = {p0[0], p0[1], p0[2]};
@@ -105,7 +103,6 @@ __global__ void __launch_bounds__(kMaxBlock) init_kernel(Consts K, InitArgs A) {
     inv_den[p] = 1.0 / (pq[p] * A.fd);  // perturbed value in the denominator, MCMC.py:264
     L[p + 1] = rsf::make_lane(pq[0], pq[1], pq[2], K);
     st[p + 1] = rsf::initial_state(pq[0], L[p + 1], K);
-    rs[p + 1] = RSF_RESYNC;
   }
   double xtx[D * D];
 #pragma unroll
@@ -124,7 +121,8 @@ __global__ void __launch_bounds__(kMaxBlock) init_kernel(Consts K, InitArgs A) {
       for (int t = 0; t <= D; ++t) ak[t] = st[t].V;
       for (int s = 0; s < K.S; ++s, j += 2) {
 #pragma unroll
-        for (int t = 0; t <= D; ++t) rsf::rk4_step<DAMP>(st[t], rs[t], lds[j], lds[j + 1], lds[j + 2], L[t], K);
+        for (int t = 0; t <= D; ++t)
+          rsf::rk4_step<DAMP>(st[t], (j & (2 * RSF_RESYNC - 1)) == 2 * RSF_RESYNC - 2, lds[j], lds[j + 1], lds[j + 2], L[t], K);
       }
 #pragma unroll
       for (int t = 0; t <= D; ++t) ak[t] = (st[t].V - ak[t]) * K.inv_dt;

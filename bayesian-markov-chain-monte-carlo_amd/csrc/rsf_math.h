@@ -17,16 +17,17 @@
 namespace rsf {
 namespace fm {
 
-// Horner step p*x + c with the coefficient c held in a register across the time loop.  Written
-// as one explicit 3-address v_fma_f64: left to itself hipcc (ROCm 7.2) selects the 2-address
-// v_fmac_f64 for these and then has to copy the loop-invariant coefficient first
-// (v_mov_b64 + v_fmac_f64 per term), which costs an extra issue slot per polynomial term.
+// Horner step p*x + c for the hot loop, with the coefficient c in a scalar register pair and the
+// instruction written as one explicit 3-address VOP3 v_fma_f64 (one SGPR source is allowed).
+// Left to itself hipcc (ROCm 7.2) selects the 2-address v_fmac_f64 for these terms and then has to
+// copy the loop-invariant coefficient into the destination first (v_mov_b64 + v_fmac_f64 per term):
+// an extra issue slot per polynomial term.
 __device__ __forceinline__ double hfma(double p, double x, double c) {
 #ifdef RSF_NO_ASM_FMA
   return __builtin_fma(p, x, c);
 #else
   double r;
-  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(p), "v"(x), "v"(c));
+  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(p), "v"(x), "s"(c));
   return r;
 #endif
 }
@@ -40,7 +41,7 @@ __device__ __forceinline__ double rcp(double x) {
 #pragma unroll
   for (int i = 0; i < RSF_RCP_NR_STEPS; ++i) {
     const double e = __builtin_fma(-x, r, 1.0);
-    r = hfma(r, e, r);
+    r = __builtin_fma(r, e, r);
   }
   return r;
 }
@@ -56,15 +57,15 @@ __device__ __forceinline__ double log(double x) {
   const double z = s * s;                      // <= 0.02944
   // 2*atanh(s) = 2s + s*z*(2/3 + 2/5 z + 2/7 z^2 + ... + 2/21 z^9); truncation < 2.2e-19
   double p = 2.0 / 21.0;
-  p = hfma(p, z, 2.0 / 19.0);
-  p = hfma(p, z, 2.0 / 17.0);
-  p = hfma(p, z, 2.0 / 15.0);
-  p = hfma(p, z, 2.0 / 13.0);
-  p = hfma(p, z, 2.0 / 11.0);
-  p = hfma(p, z, 2.0 / 9.0);
-  p = hfma(p, z, 2.0 / 7.0);
-  p = hfma(p, z, 2.0 / 5.0);
-  p = hfma(p, z, 2.0 / 3.0);
+  p = __builtin_fma(p, z, 2.0 / 19.0);
+  p = __builtin_fma(p, z, 2.0 / 17.0);
+  p = __builtin_fma(p, z, 2.0 / 15.0);
+  p = __builtin_fma(p, z, 2.0 / 13.0);
+  p = __builtin_fma(p, z, 2.0 / 11.0);
+  p = __builtin_fma(p, z, 2.0 / 9.0);
+  p = __builtin_fma(p, z, 2.0 / 7.0);
+  p = __builtin_fma(p, z, 2.0 / 5.0);
+  p = __builtin_fma(p, z, 2.0 / 3.0);
   const double lm = __builtin_fma(s * z, p, s + s);
   const double r = __builtin_fma((double)e, 0.69314718055994530942, lm);
   return x > 0.0 ? r : __builtin_nan("");
@@ -76,16 +77,16 @@ __device__ __forceinline__ double exp(double x) {
   r = __builtin_fma(-k, 0x1.ef35793c7673p-45, r);           // ln2 low part
   // |r| <= 0.3466: Taylor to r^13/13!, truncation < 5e-18 relative
   double p = 1.0 / 6227020800.0;
-  p = hfma(p, r, 1.0 / 479001600.0);
-  p = hfma(p, r, 1.0 / 39916800.0);
-  p = hfma(p, r, 1.0 / 3628800.0);
-  p = hfma(p, r, 1.0 / 362880.0);
-  p = hfma(p, r, 1.0 / 40320.0);
-  p = hfma(p, r, 1.0 / 5040.0);
-  p = hfma(p, r, 1.0 / 720.0);
-  p = hfma(p, r, 1.0 / 120.0);
-  p = hfma(p, r, 1.0 / 24.0);
-  p = hfma(p, r, 1.0 / 6.0);
+  p = __builtin_fma(p, r, 1.0 / 479001600.0);
+  p = __builtin_fma(p, r, 1.0 / 39916800.0);
+  p = __builtin_fma(p, r, 1.0 / 3628800.0);
+  p = __builtin_fma(p, r, 1.0 / 362880.0);
+  p = __builtin_fma(p, r, 1.0 / 40320.0);
+  p = __builtin_fma(p, r, 1.0 / 5040.0);
+  p = __builtin_fma(p, r, 1.0 / 720.0);
+  p = __builtin_fma(p, r, 1.0 / 120.0);
+  p = __builtin_fma(p, r, 1.0 / 24.0);
+  p = __builtin_fma(p, r, 1.0 / 6.0);
   p = __builtin_fma(p, r, 0.5);
   p = __builtin_fma(p, r, 1.0);
   p = __builtin_fma(p, r, 1.0);
