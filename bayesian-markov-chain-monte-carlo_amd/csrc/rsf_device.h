@@ -42,6 +42,8 @@ struct Lane {
   double b;
   double boa;     // b/a
   double tc;      // -mu_ref/a
+  double c_l1p;   // -1/6 and 1/5040: leading series coefficients kept in VGPRs (a VOP3 takes one SGPR source,
+  double c_em1;   //   and the first Horner term has two non-inline constants)
 };
 
 __device__ __forceinline__ Lane make_lane(double dc, double a, double b, const Consts &K) {
@@ -55,6 +57,9 @@ __device__ __forceinline__ Lane make_lane(double dc, double a, double b, const C
   L.b = b;
   L.boa = b * L.inv_a;
   L.tc = -K.mu_ref * L.inv_a;
+  L.c_l1p = -1.0 / 6.0;
+  L.c_em1 = 1.0 / 5040.0;
+  asm volatile("" : "+v"(L.c_l1p), "+v"(L.c_em1));  // opaque: stays a register value, not re-materialised per step
   return L;
 }
 
@@ -98,7 +103,7 @@ __device__ __forceinline__ void eval_full(double mu, double th, const Lane &L, d
 
 // (w', 1/th') at (mu + dmu, th1 = th + dth) from (w, rth) at (mu, th).  With rho = dth/th and
 // dlt = dmu/a - (b/a) log1p(rho):   w' = w exp(dlt),   1/th' = (1/th)/(1 + rho),
-// by short series — the same function of (mu', th') to rounding while |rho|, |dmu/a| < 2^-8
+// by short series — the same function of (mu', th') to rounding while |rho|, |dmu/a| < 2^-9
 // (truncation < 1e-17).  `big` tracks the largest increment seen.
 __device__ __forceinline__ void eval_incr(double dmu, double dth, double th1, const Lane &L, double w0, double rth0,
                                           double &w, double &rth, double &big) {
@@ -106,28 +111,23 @@ __device__ __forceinline__ void eval_incr(double dmu, double dth, double th1, co
   const double dm = dmu * L.inv_a;
   big = __builtin_fmax(big, __builtin_fmax(__builtin_fabs(rho), __builtin_fabs(dm)));
   // log1p(rho) = rho - rho^2/2 + ... - rho^6/6              (next term < 2^-56/7)
-  double p = -1.0 / 6.0;
-  p = fm::hfma(p, rho, 1.0 / 5.0);
+  double p = fm::hfma(L.c_l1p, rho, 1.0 / 5.0);
   p = fm::hfma(p, rho, -1.0 / 4.0);
   p = fm::hfma(p, rho, 1.0 / 3.0);
   p = __builtin_fma(p, rho, -0.5);
   p = __builtin_fma(p, rho, 1.0);
   const double dlt = __builtin_fma(-L.boa, p * rho, dm);
   // expm1(dlt) = dlt + dlt^2/2 + ... + dlt^7/5040          (next term < 1e-19 for |dlt| < 2^-6)
-  double e = 1.0 / 5040.0;
-  e = fm::hfma(e, dlt, 1.0 / 720.0);
+  double e = fm::hfma(L.c_em1, dlt, 1.0 / 720.0);
   e = fm::hfma(e, dlt, 1.0 / 120.0);
   e = fm::hfma(e, dlt, 1.0 / 24.0);
   e = fm::hfma(e, dlt, 1.0 / 6.0);
   e = __builtin_fma(e, dlt, 0.5);
   e = __builtin_fma(e, dlt, 1.0);
   w = __builtin_fma(w0, e * dlt, w0);
-  // 1/th' from 1/th: first-order start (error rho^2 < 2^-16), two Newton steps (-> 2^-64)
-  rth = __builtin_fma(-rho, rth0, rth0);
-  double r = __builtin_fma(-th1, rth, 1.0);
-  rth = __builtin_fma(rth, r, rth);
-  r = __builtin_fma(-th1, rth, 1.0);
-  rth = __builtin_fma(rth, r, rth);
+  // 1/th' from 1/th: second-order start rth0 (1 - rho + rho^2) (error rho^3 < 2^-27), one Newton step (-> 2^-54)
+  rth = __builtin_fma(rth0, __builtin_fma(rho, rho, -rho), rth0);
+  rth = __builtin_fma(rth, __builtin_fma(-th1, rth, 1.0), rth);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -137,7 +137,7 @@ __device__ __forceinline__ void eval_incr(double dmu, double dth, double th1, co
 // transcendental at all; stages 2-4 and the step's end point are reached by eval_incr from the
 // step's start point.  Straight-line code on purpose: with one wave per SIMD (cfg1) every
 // instruction, nop and branch costs a full ~5-cycle issue slot (tools/microbench_fp64.hip).
-// The largest relative increment of the step is checked ONCE; if a lane exceeded 2^-8 (stiff
+// The largest relative increment of the step is checked ONCE; if a lane exceeded 2^-9 (stiff
 // small-Dc proposals) the step is redone from the saved start point with full evaluations
 // (rk4_cold).  Every RSF_RESYNC steps (w, 1/th) are recomputed in full so rounding in the
 // incremental products cannot accumulate (1/th is self-correcting through its Newton steps).
@@ -168,7 +168,6 @@ __device__ __forceinline__ void rk4_cold(State &s, double vl0, double vlm, doubl
   s.mu = __builtin_fma(K.h6, s0, s.mu);
   s.th = __builtin_fma(K.h6, s1, s.th);
   s.V = __builtin_fma(K.h6, s2, s.V);
-  eval_full(s.mu, s.th, L, s.w, s.rth);
 }
 
 template <bool DAMP>
@@ -202,14 +201,16 @@ __device__ __forceinline__ void rk4_step(State &s, bool resync, double vl0, doub
                                          const Consts &K) {
 #ifdef RSF_NO_INCREMENTAL
   rk4_cold<DAMP>(s, vl0, vlm, vl1, L, K);
+  (void)resync;
 #else
   if (resync) eval_full(s.mu, s.th, L, s.w, s.rth);
   const State save = s;
   double big = 0.0;
   rk4_fast<DAMP>(s, vl0, vlm, vl1, L, K, big);
-  if (__builtin_expect(!(big < 0x1.0p-8), 0)) {  // an increment too large (or Inf; NaN passes through): cold path
+  if (__builtin_expect(!(big < 0x1.0p-9), 0)) {  // an increment too large (or Inf; NaN passes through): cold path
     s = save;
     rk4_cold<DAMP>(s, vl0, vlm, vl1, L, K);
+    eval_full(s.mu, s.th, L, s.w, s.rth);
   }
 #endif
 }
@@ -248,12 +249,45 @@ template <bool DAMP, bool WANT_SSQ, bool WANT_ACC>
 __device__ __forceinline__ void integrate_chunk(const double *lds, const Consts &K, const Lane &L, int k0,
                                                 int kn, State &s, double &ssq, double *acc_out, int64_t stride) {
   const double *ld = lds + lds_data_offset(K);
-  if (K.S == 1) {  // one step per output sample: flat loop
-    for (int kk = 0; kk < kn; ++kk) {
+#ifndef RSF_NO_INCREMENTAL
+  if (K.S == 1) {
+    // One step per output sample (the BASELINE configs): steps go in PAIRS through straight-line code, so loop
+    // control, the resync test, the increment guard and the LDS address are paid once per two steps and no
+    // register copies are needed to rotate the state.  A failed guard redoes the pair from `save`; an odd last
+    // step takes the full-evaluation path.
+    int kk = 0;
+    for (; kk + 2 <= kn; kk += 2) {
+      const double *v = lds + 2 * kk;
+      if ((kk & (RSF_RESYNC - 1)) == 0) eval_full(s.mu, s.th, L, s.w, s.rth);
+      const State save = s;
+      double big = 0.0;
+      rk4_fast<DAMP>(s, v[0], v[1], v[2], L, K, big);
+      double vmid = s.V;
+      rk4_fast<DAMP>(s, v[2], v[3], v[4], L, K, big);
+      if (__builtin_expect(!(big < 0x1.0p-9), 0)) {  // too large (or Inf; NaN passes through): cold path
+        s = save;
+        rk4_cold<DAMP>(s, v[0], v[1], v[2], L, K);
+        vmid = s.V;
+        rk4_cold<DAMP>(s, v[2], v[3], v[4], L, K);
+        eval_full(s.mu, s.th, L, s.w, s.rth);
+      }
+      const double ak0 = (vmid - save.V) * K.inv_dt, ak1 = (s.V - vmid) * K.inv_dt;  // RateStateModel.py:388
+      if (WANT_ACC) {
+        acc_out[(int64_t)(k0 + kk) * stride] = ak0;
+        acc_out[(int64_t)(k0 + kk + 1) * stride] = ak1;
+      }
+      if (WANT_SSQ) {
+        const double r0 = ak0 - ld[kk], r1 = ak1 - ld[kk + 1];
+        ssq += r0 * r0;
+        ssq += r1 * r1;
+      }
+    }
+    if (kk < kn) {
+      const double *v = lds + 2 * kk;
       const double vprev = s.V;
-      const int j = 2 * kk;
-      rk4_step<DAMP>(s, (kk & (RSF_RESYNC - 1)) == RSF_RESYNC - 1, lds[j], lds[j + 1], lds[j + 2], L, K);
-      const double ak = (s.V - vprev) * K.inv_dt;  // RateStateModel.py:388
+      rk4_cold<DAMP>(s, v[0], v[1], v[2], L, K);
+      eval_full(s.mu, s.th, L, s.w, s.rth);
+      const double ak = (s.V - vprev) * K.inv_dt;
       if (WANT_ACC) acc_out[(int64_t)(k0 + kk) * stride] = ak;
       if (WANT_SSQ) {
         const double r = ak - ld[kk];
@@ -262,6 +296,7 @@ __device__ __forceinline__ void integrate_chunk(const double *lds, const Consts 
     }
     return;
   }
+#endif
   int j = 0;
   for (int kk = 0; kk < kn; ++kk) {
     const double vprev = s.V;

@@ -17,13 +17,13 @@
 namespace rsf {
 namespace fm {
 
-// Horner step p*x + c for the hot loop, with the coefficient c in a scalar register pair and the
-// instruction written as one explicit 3-address VOP3 v_fma_f64 (one SGPR source is allowed).
-// Left to itself hipcc (ROCm 7.2) selects the 2-address v_fmac_f64 for these terms and then has to
-// copy the loop-invariant coefficient into the destination first (v_mov_b64 + v_fmac_f64 per term):
-// an extra issue slot per polynomial term.
+// Horner step p*x + c of the hot-loop series.  Plain fma: with the full log/exp out of the hot loop its
+// nine coefficients stay in SGPRs and hipcc emits one 3-address v_fma_f64 v, v, v, s[..] per term.
+// (Earlier, with ~35 live constants, it fell back to v_mov_b64 + 2-address v_fmac_f64 per term; the
+// explicit-asm form below fixed that but costs an s_nop after each asm statement, so it is now only an
+// A/B switch: -DRSF_ASM_FMA.)
 __device__ __forceinline__ double hfma(double p, double x, double c) {
-#ifdef RSF_NO_ASM_FMA
+#ifndef RSF_ASM_FMA
   return __builtin_fma(p, x, c);
 #else
   double r;

@@ -11,8 +11,9 @@
 
 constexpr int ITERS = 60000;
 
-template <int OP, int ILP>
+template <int OP, int ILP, int ACTIVE = 64>
 __global__ void __launch_bounds__(256) bench(double *out, unsigned long long *cyc, unsigned long long *rt, double seed) {
+  if ((threadIdx.x & 63) >= ACTIVE) return;  // leave only the first ACTIVE lanes of each wave64 running
   double r[ILP];
 #pragma unroll
   for (int i = 0; i < ILP; ++i) r[i] = seed + i * 1e-3 + threadIdx.x * 1e-6;
@@ -49,7 +50,7 @@ __global__ void __launch_bounds__(256) bench(double *out, unsigned long long *cy
   if (threadIdx.x == 0) { cyc[blockIdx.x] = t1 - t0; rt[blockIdx.x] = r1 - r0; }
 }
 
-template <int OP, int ILP>
+template <int OP, int ILP, int ACTIVE = 64>
 int run(const char *name, int waves_per_simd) {
   const int blocks = 256 * waves_per_simd;  // 256 CUs, 256-thread blocks = one wave per SIMD per block
   double *out;
@@ -60,10 +61,10 @@ int run(const char *name, int waves_per_simd) {
   hipEvent_t e0, e1;
   CHECK(hipEventCreate(&e0));
   CHECK(hipEventCreate(&e1));
-  hipLaunchKernelGGL((bench<OP, ILP>), dim3(blocks), dim3(256), 0, nullptr, out, cyc, rt, 1.0);
+  hipLaunchKernelGGL((bench<OP, ILP, ACTIVE>), dim3(blocks), dim3(256), 0, nullptr, out, cyc, rt, 1.0);
   CHECK(hipDeviceSynchronize());
   CHECK(hipEventRecord(e0));
-  hipLaunchKernelGGL((bench<OP, ILP>), dim3(blocks), dim3(256), 0, nullptr, out, cyc, rt, 1.0);
+  hipLaunchKernelGGL((bench<OP, ILP, ACTIVE>), dim3(blocks), dim3(256), 0, nullptr, out, cyc, rt, 1.0);
   CHECK(hipEventRecord(e1));
   CHECK(hipEventSynchronize(e1));
   float ms;
@@ -78,7 +79,7 @@ int run(const char *name, int waves_per_simd) {
   mean /= blocks;
   mrt /= blocks;
   const double n = (double)ITERS * 16;
-  printf("%-14s ILP=%d waves/SIMD=%d : memtime %6.2f ticks/instr/wave (%5.2f per SIMD) ; in-kernel %.3f ms (realtime@100MHz) wall %.3f ms ; memtime rate %.3f GHz ; %.3f ns per instr per SIMD\n", name, ILP,
+  printf("%-14s act=%d ILP=%d waves/SIMD=%d : memtime %6.2f ticks/instr/wave (%5.2f per SIMD) ; in-kernel %.3f ms (realtime@100MHz) wall %.3f ms ; memtime rate %.3f GHz ; %.3f ns per instr per SIMD\n", name, ACTIVE, ILP,
          waves_per_simd, mean / n, mean / n / waves_per_simd, mrt / 1e5, ms, mean / (mrt * 10.0), mrt * 10.0 / n / waves_per_simd);
   (void)hipFree(out);
   (void)hipFree(cyc);
@@ -87,15 +88,12 @@ int run(const char *name, int waves_per_simd) {
 }
 
 int main() {
-  for (int w : {1, 2, 4, 8}) { run<0, 1>("v_fma_f64", w); run<0, 4>("v_fma_f64", w); }
-  for (int w : {1, 4}) {
-    run<1, 4>("v_mul_f64", w);
-    run<3, 4>("v_rcp_f64", w);
-    run<4, 4>("v_ldexp_f64", w);
-    run<7, 4>("v_mov_b64", w);
-    run<8, 4>("v_fma_f32", w);
-    run<11, 4>("v_cndmask_b32", w);
-    run<10, 4>("nop+fma_f64", w);
-  }
+  // does the SIMD skip inactive 16/32-lane groups of a wave64 for fp64 ops?
+  run<0, 1, 64>("v_fma_f64", 1); run<0, 4, 64>("v_fma_f64", 1);
+  run<0, 1, 32>("v_fma_f64", 1); run<0, 4, 32>("v_fma_f64", 1);
+  run<0, 1, 16>("v_fma_f64", 1); run<0, 4, 16>("v_fma_f64", 1);
+  run<0, 1, 32>("v_fma_f64", 2); run<0, 4, 32>("v_fma_f64", 2);
+  run<0, 1, 16>("v_fma_f64", 4); run<0, 4, 16>("v_fma_f64", 4);
+  run<0, 4, 64>("v_fma_f64", 2);
   return 0;
 }
