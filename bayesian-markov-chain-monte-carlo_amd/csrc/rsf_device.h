@@ -42,8 +42,8 @@ struct Lane {
   double b;
   double boa;     // b/a
   double tc;      // -mu_ref/a
-  double c_l1p;   // -1/6 and 1/5040: leading series coefficients kept in VGPRs (a VOP3 takes one SGPR source,
-  double c_em1;   //   and the first Horner term has two non-inline constants)
+  double c_l1p;   // leading series coefficients kept in VGPRs (a VOP3 takes one SGPR source and the first Horner
+  double c_em1;   //   term has two non-inline constants): log1p 1/7 (wide) or -1/6 (narrow); expm1 1/5040
 };
 
 __device__ __forceinline__ Lane make_lane(double dc, double a, double b, const Consts &K) {
@@ -57,7 +57,7 @@ __device__ __forceinline__ Lane make_lane(double dc, double a, double b, const C
   L.b = b;
   L.boa = b * L.inv_a;
   L.tc = -K.mu_ref * L.inv_a;
-  L.c_l1p = -1.0 / 6.0;
+  L.c_l1p = 1.0 / 7.0;
   L.c_em1 = 1.0 / 5040.0;
   asm volatile("" : "+v"(L.c_l1p), "+v"(L.c_em1));  // opaque: stays a register value, not re-materialised per step
   return L;
@@ -103,21 +103,33 @@ __device__ __forceinline__ void eval_full(double mu, double th, const Lane &L, d
 
 // (w', 1/th') at (mu + dmu, th1 = th + dth) from (w, rth) at (mu, th).  With rho = dth/th and
 // dlt = dmu/a - (b/a) log1p(rho):   w' = w exp(dlt),   1/th' = (1/th)/(1 + rho),
-// by short series — the same function of (mu', th') to rounding while |rho|, |dmu/a| < 2^-9
-// (truncation < 1e-17).  `big` tracks the largest increment seen.
+// by short series — the same function of (mu', th') to rounding inside the guard region:
+//   |dlt| < 2^-6 : expm1 to dlt^7/5040                      (next term < 9e-20)
+//   NARROW |rho| < 2^-9 : log1p to rho^6/6, 1/th' by a 2nd-order start + 1 Newton step (rho^6 < 2^-54)
+//   WIDE   |rho| < 2^-7 : log1p to rho^7/7, 1/th' by a 1st-order start + 2 Newton steps (rho^8 < 2^-56)
+// `grho` / `gdlt` track the largest |rho| / |dlt| seen since they were last reset.
+struct Guard {
+  double rho, dlt;
+};
+
+template <bool WIDE>
 __device__ __forceinline__ void eval_incr(double dmu, double dth, double th1, const Lane &L, double w0, double rth0,
-                                          double &w, double &rth, double &big) {
+                                          double &w, double &rth, Guard &g) {
   const double rho = dth * rth0;
-  const double dm = dmu * L.inv_a;
-  big = __builtin_fmax(big, __builtin_fmax(__builtin_fabs(rho), __builtin_fabs(dm)));
-  // log1p(rho) = rho - rho^2/2 + ... - rho^6/6              (next term < 2^-56/7)
-  double p = fm::hfma(L.c_l1p, rho, 1.0 / 5.0);
+  g.rho = __builtin_fmax(g.rho, __builtin_fabs(rho));
+  double p;
+  if (WIDE) {
+    p = fm::hfma(L.c_l1p, rho, -1.0 / 6.0);  // c_l1p = 1/7
+    p = fm::hfma(p, rho, 1.0 / 5.0);
+  } else {
+    p = fm::hfma(L.c_l1p, rho, 1.0 / 5.0);   // c_l1p = -1/6
+  }
   p = fm::hfma(p, rho, -1.0 / 4.0);
   p = fm::hfma(p, rho, 1.0 / 3.0);
   p = __builtin_fma(p, rho, -0.5);
   p = __builtin_fma(p, rho, 1.0);
-  const double dlt = __builtin_fma(-L.boa, p * rho, dm);
-  // expm1(dlt) = dlt + dlt^2/2 + ... + dlt^7/5040          (next term < 1e-19 for |dlt| < 2^-6)
+  const double dlt = __builtin_fma(-L.boa, p * rho, dmu * L.inv_a);
+  g.dlt = __builtin_fmax(g.dlt, __builtin_fabs(dlt));
   double e = fm::hfma(L.c_em1, dlt, 1.0 / 720.0);
   e = fm::hfma(e, dlt, 1.0 / 120.0);
   e = fm::hfma(e, dlt, 1.0 / 24.0);
@@ -125,9 +137,19 @@ __device__ __forceinline__ void eval_incr(double dmu, double dth, double th1, co
   e = __builtin_fma(e, dlt, 0.5);
   e = __builtin_fma(e, dlt, 1.0);
   w = __builtin_fma(w0, e * dlt, w0);
-  // 1/th' from 1/th: second-order start rth0 (1 - rho + rho^2) (error rho^3 < 2^-27), one Newton step (-> 2^-54)
-  rth = __builtin_fma(rth0, __builtin_fma(rho, rho, -rho), rth0);
-  rth = __builtin_fma(rth, __builtin_fma(-th1, rth, 1.0), rth);
+  if (WIDE) {
+    rth = __builtin_fma(-rho, rth0, rth0);
+    rth = __builtin_fma(rth, __builtin_fma(-th1, rth, 1.0), rth);
+    rth = __builtin_fma(rth, __builtin_fma(-th1, rth, 1.0), rth);
+  } else {
+    rth = __builtin_fma(rth0, __builtin_fma(rho, rho, -rho), rth0);
+    rth = __builtin_fma(rth, __builtin_fma(-th1, rth, 1.0), rth);
+  }
+}
+
+template <bool WIDE>
+__device__ __forceinline__ bool guard_ok(const Guard &g) {
+  return (g.rho < (WIDE ? 0x1.0p-7 : 0x1.0p-9)) && (g.dlt < 0x1.0p-6);  // false for Inf; NaN passes through
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -170,24 +192,24 @@ __device__ __forceinline__ void rk4_cold(State &s, double vl0, double vlm, doubl
   s.V = __builtin_fma(K.h6, s2, s.V);
 }
 
-template <bool DAMP>
+template <bool DAMP, bool WIDE>
 __device__ __forceinline__ void rk4_fast(State &s, double vl0, double vlm, double vl1, const Lane &L,
-                                         const Consts &K, double &big) {
+                                         const Consts &K, Guard &g) {
   double a0, a1, a2, b0, b1, b2, c0, c1, c2, e0, e1, e2, w, rth;
   rhs_tail<DAMP>(s.w, s.rth, s.th, vl0, L, K, a0, a1, a2);
   double dth = K.hh * a1;
-  eval_incr(K.hh * a0, dth, s.th + dth, L, s.w, s.rth, w, rth, big);
+  eval_incr<WIDE>(K.hh * a0, dth, s.th + dth, L, s.w, s.rth, w, rth, g);
   rhs_tail<DAMP>(w, rth, s.th + dth, vlm, L, K, b0, b1, b2);
   dth = K.hh * b1;
-  eval_incr(K.hh * b0, dth, s.th + dth, L, s.w, s.rth, w, rth, big);
+  eval_incr<WIDE>(K.hh * b0, dth, s.th + dth, L, s.w, s.rth, w, rth, g);
   rhs_tail<DAMP>(w, rth, s.th + dth, vlm, L, K, c0, c1, c2);
   dth = K.h * c1;
-  eval_incr(K.h * c0, dth, s.th + dth, L, s.w, s.rth, w, rth, big);
+  eval_incr<WIDE>(K.h * c0, dth, s.th + dth, L, s.w, s.rth, w, rth, g);
   rhs_tail<DAMP>(w, rth, s.th + dth, vl1, L, K, e0, e1, e2);
   const double dmu = K.h6 * (a0 + 2.0 * b0 + 2.0 * c0 + e0);
   dth = K.h6 * (a1 + 2.0 * b1 + 2.0 * c1 + e1);
   const double th1 = s.th + dth;
-  eval_incr(dmu, dth, th1, L, s.w, s.rth, w, rth, big);
+  eval_incr<WIDE>(dmu, dth, th1, L, s.w, s.rth, w, rth, g);
   s.mu = s.mu + dmu;
   s.th = th1;
   s.V = s.V + K.h6 * (a2 + 2.0 * b2 + 2.0 * c2 + e2);
@@ -205,9 +227,9 @@ __device__ __forceinline__ void rk4_step(State &s, bool resync, double vl0, doub
 #else
   if (resync) eval_full(s.mu, s.th, L, s.w, s.rth);
   const State save = s;
-  double big = 0.0;
-  rk4_fast<DAMP>(s, vl0, vlm, vl1, L, K, big);
-  if (__builtin_expect(!(big < 0x1.0p-9), 0)) {  // an increment too large (or Inf; NaN passes through): cold path
+  Guard g = {0.0, 0.0};
+  rk4_fast<DAMP, true>(s, vl0, vlm, vl1, L, K, g);
+  if (__builtin_expect(!guard_ok<true>(g), 0)) {  // an increment too large (or Inf; NaN passes through): cold path
     s = save;
     rk4_cold<DAMP>(s, vl0, vlm, vl1, L, K);
     eval_full(s.mu, s.th, L, s.w, s.rth);
@@ -229,7 +251,8 @@ __device__ __forceinline__ State initial_state(double dc, const Lane &L, const C
 // 2*S*kn+1 loading values and kn observations.  Layout: [ vl : 2*S*kc+1 ][ data : kc ].
 // Every thread of the workgroup must call stage_chunk (it contains the barriers).
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ int lds_data_offset(const Consts &K) { return 2 * K.S * K.kc + 1; }
+constexpr int kLdsPad = 0;
+__device__ __forceinline__ int lds_data_offset(const Consts &K) { return 2 * K.S * K.kc + 1 + kLdsPad; }
 
 __device__ __forceinline__ void stage_chunk(double *lds, const Consts &K, int k0, int kn) {
   const int nv = 2 * K.S * kn + 1;
@@ -243,6 +266,59 @@ __device__ __forceinline__ void stage_chunk(double *lds, const Consts &K, int k0
   __syncthreads();
 }
 
+// One step per output sample (the BASELINE configs): steps go in PAIRS through straight-line code, so loop
+// control, the resync test, the increment guard and the LDS address are paid once per two steps and no register
+// copies are needed to rotate the state.  A failed guard redoes the pair from `save` with full evaluations; an
+// odd last step takes the full-evaluation path as well.
+template <bool DAMP, bool WANT_SSQ, bool WANT_ACC, bool WIDE>
+__device__ __forceinline__ void integrate_pairs(const double *lds, const double *ld, const Consts &K, Lane L, int k0,
+                                                int kn, State &s, double &ssq, double *acc_out, int64_t stride) {
+  if (!WIDE) {
+    L.c_l1p = -1.0 / 6.0;
+    asm volatile("" : "+v"(L.c_l1p));
+  }
+  int kk = 0;
+  for (; kk + 2 <= kn; kk += 2) {
+    const double *v = lds + 2 * kk;
+    const double dd0 = ld[kk], dd1 = ld[kk + 1];
+    if ((kk & (RSF_RESYNC - 1)) == 0) eval_full(s.mu, s.th, L, s.w, s.rth);
+    const State save = s;
+    Guard g = {0.0, 0.0};
+    rk4_fast<DAMP, WIDE>(s, v[0], v[1], v[2], L, K, g);
+    double vmid = s.V;
+    rk4_fast<DAMP, WIDE>(s, v[2], v[3], v[4], L, K, g);
+    if (__builtin_expect(!guard_ok<WIDE>(g), 0)) {
+      s = save;
+      rk4_cold<DAMP>(s, v[0], v[1], v[2], L, K);
+      vmid = s.V;
+      rk4_cold<DAMP>(s, v[2], v[3], v[4], L, K);
+      eval_full(s.mu, s.th, L, s.w, s.rth);
+    }
+    const double ak0 = (vmid - save.V) * K.inv_dt, ak1 = (s.V - vmid) * K.inv_dt;  // RateStateModel.py:388
+    if (WANT_ACC) {
+      acc_out[(int64_t)(k0 + kk) * stride] = ak0;
+      acc_out[(int64_t)(k0 + kk + 1) * stride] = ak1;
+    }
+    if (WANT_SSQ) {
+      const double r0 = ak0 - dd0, r1 = ak1 - dd1;
+      ssq += r0 * r0;
+      ssq += r1 * r1;
+    }
+  }
+  if (kk < kn) {
+    const double *v = lds + 2 * kk;
+    const double vprev = s.V;
+    rk4_cold<DAMP>(s, v[0], v[1], v[2], L, K);
+    eval_full(s.mu, s.th, L, s.w, s.rth);
+    const double ak = (s.V - vprev) * K.inv_dt;
+    if (WANT_ACC) acc_out[(int64_t)(k0 + kk) * stride] = ak;
+    if (WANT_SSQ) {
+      const double r = ak - ld[kk];
+      ssq += r * r;
+    }
+  }
+}
+
 // Integrate kn output intervals from the staged chunk.  Accumulates the sum of squares
 // (MCMC.py:387) and optionally stores acc time-major.  Called under the lane's activity mask.
 template <bool DAMP, bool WANT_SSQ, bool WANT_ACC>
@@ -251,49 +327,15 @@ __device__ __forceinline__ void integrate_chunk(const double *lds, const Consts 
   const double *ld = lds + lds_data_offset(K);
 #ifndef RSF_NO_INCREMENTAL
   if (K.S == 1) {
-    // One step per output sample (the BASELINE configs): steps go in PAIRS through straight-line code, so loop
-    // control, the resync test, the increment guard and the LDS address are paid once per two steps and no
-    // register copies are needed to rotate the state.  A failed guard redoes the pair from `save`; an odd last
-    // step takes the full-evaluation path.
-    int kk = 0;
-    for (; kk + 2 <= kn; kk += 2) {
-      const double *v = lds + 2 * kk;
-      if ((kk & (RSF_RESYNC - 1)) == 0) eval_full(s.mu, s.th, L, s.w, s.rth);
-      const State save = s;
-      double big = 0.0;
-      rk4_fast<DAMP>(s, v[0], v[1], v[2], L, K, big);
-      double vmid = s.V;
-      rk4_fast<DAMP>(s, v[2], v[3], v[4], L, K, big);
-      if (__builtin_expect(!(big < 0x1.0p-9), 0)) {  // too large (or Inf; NaN passes through): cold path
-        s = save;
-        rk4_cold<DAMP>(s, v[0], v[1], v[2], L, K);
-        vmid = s.V;
-        rk4_cold<DAMP>(s, v[2], v[3], v[4], L, K);
-        eval_full(s.mu, s.th, L, s.w, s.rth);
-      }
-      const double ak0 = (vmid - save.V) * K.inv_dt, ak1 = (s.V - vmid) * K.inv_dt;  // RateStateModel.py:388
-      if (WANT_ACC) {
-        acc_out[(int64_t)(k0 + kk) * stride] = ak0;
-        acc_out[(int64_t)(k0 + kk + 1) * stride] = ak1;
-      }
-      if (WANT_SSQ) {
-        const double r0 = ak0 - ld[kk], r1 = ak1 - ld[kk + 1];
-        ssq += r0 * r0;
-        ssq += r1 * r1;
-      }
-    }
-    if (kk < kn) {
-      const double *v = lds + 2 * kk;
-      const double vprev = s.V;
-      rk4_cold<DAMP>(s, v[0], v[1], v[2], L, K);
-      eval_full(s.mu, s.th, L, s.w, s.rth);
-      const double ak = (s.V - vprev) * K.inv_dt;
-      if (WANT_ACC) acc_out[(int64_t)(k0 + kk) * stride] = ak;
-      if (WANT_SSQ) {
-        const double r = ak - ld[kk];
-        ssq += r * r;
-      }
-    }
+    // wave-uniform choice of the series variant from a bound on |dth/th| (<= 4 h / Dc while v <= 2 V_ref);
+    // either variant is exact to rounding inside its guard, so this is a speed decision only
+#ifdef RSF_FORCE_NARROW
+    const bool wide = false;
+#else
+    const bool wide = __any(!(4.0 * K.h * L.inv_dc < 0x1.0p-9));
+#endif
+    if (wide) integrate_pairs<DAMP, WANT_SSQ, WANT_ACC, true>(lds, ld, K, L, k0, kn, s, ssq, acc_out, stride);
+    else integrate_pairs<DAMP, WANT_SSQ, WANT_ACC, false>(lds, ld, K, L, k0, kn, s, ssq, acc_out, stride);
     return;
   }
 #endif

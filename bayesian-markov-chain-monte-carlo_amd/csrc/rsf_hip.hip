@@ -598,7 +598,7 @@ int rsf_set_model(rsf_ctx *c, const rsf_model *m) {
   const int S = m->substeps;
   const double h = delta_t / S, hh = 0.5 * h;
   // LDS chunking: kc output intervals need (2*S*kc + 1) loading values + kc observations
-  const size_t words = kLdsBudget / sizeof(double);
+  const size_t words = kLdsBudget / sizeof(double) - 2 * rsf::kLdsPad;
   int64_t kc = ((int64_t)words - 1) / (2 * (int64_t)S + 1);
   if (kc < 1) return fail(RSF_ERR_UNSUPPORTED, "rsf_set_model: substeps=%d does not fit the LDS staging budget", S);
   if (kc > nout - 1) kc = nout - 1;
@@ -618,7 +618,7 @@ int rsf_set_model(rsf_ctx *c, const rsf_model *m) {
   c->delta_t = delta_t; c->h = h; c->nout = nout;
   c->kc = (int32_t)kc;
   c->nchunks = (int32_t)((nout - 1 + kc - 1) / kc);
-  c->lds_bytes = (size_t)(2 * S * kc + 1 + kc) * sizeof(double);
+  c->lds_bytes = (size_t)(2 * S * kc + 1 + kc + 2 * rsf::kLdsPad) * sizeof(double);
   c->have_model = true;
   return RSF_OK;
 }
