@@ -34,7 +34,7 @@ def init_process_group(backend=None):
     if backend is None:
         backend = "nccl" if torch.cuda.is_available() else "gloo"
     if backend == "nccl":
-        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", rank)))
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", rank)) % max(1, torch.cuda.device_count()))
     dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world
 

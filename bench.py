@@ -68,10 +68,11 @@ def cpu_baseline(model, data, target_s=12.0):
     with pkg.Engine(lib=lib, cpu_threads=cores) as e:
         nout = e.set_model(model, 1)
         e.mcmc_init(np.full((chains, 1), 1000.0), data, [0.0], [1.0e4], seed=2025, prior_len=3)
+        e.mcmc_run(1, traces=False)  # thread-pool warm-up
         t0 = time.perf_counter()
-        e.mcmc_run(2, traces=False)
-        per_iter = (time.perf_counter() - t0) / 2
-        iters = int(max(4, min(400, target_s / max(per_iter, 1e-6))))
+        e.mcmc_run(3, traces=False)
+        per_iter = (time.perf_counter() - t0) / 3
+        iters = int(max(4, min(2000, target_s / max(per_iter, 1e-6))))
         t0 = time.perf_counter()
         e.mcmc_run(iters, traces=("q", "std2"))
         wall = time.perf_counter() - t0
@@ -91,6 +92,8 @@ def main():
     ap.add_argument("--nsteps", type=int, default=0)
     ap.add_argument("--iters-per-step", type=int, default=10, help="proposals per chain per launch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="collective backend for N > 1 (nccl = RCCL; gloo only to rehearse the N > 1 path on one GPU)")
     args = ap.parse_args()
 
     import torch
@@ -102,10 +105,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", 1))
     rank = int(os.environ.get("RANK", 0))
     if world > 1:
-        rank, world = rdist.init_process_group("nccl")
+        rank, world = rdist.init_process_group(args.backend)
     elif args.gpus > 1:
         raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
-    torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", 0)))
+    torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", 0)) % torch.cuda.device_count())
+    coll_dev = "cuda" if args.backend == "nccl" else "cpu"  # gloo rehearsal moves the collectives' tensors to the host
 
     wl = WORKLOADS[args.workload]
     C = args.chains or wl["chains"]          # per GPU: weak scaling
@@ -141,13 +145,13 @@ def main():
     stats = eng.stats()
 
     if world > 1:
-        t = torch.tensor([wall], dtype=torch.float64, device="cuda")
+        t = torch.tensor([wall], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall = float(t.item())
         # the path's only collective: pool the last block of samples from every GPU (RCCL all-gather)
         torch.cuda.synchronize()
         g0 = time.perf_counter()
-        pool = rdist.pool_to_chain_major(rdist.allgather_pool(traces[0]))
+        pool = rdist.pool_to_chain_major(rdist.allgather_pool(traces[0].to(coll_dev)))
         torch.cuda.synchronize()
         allgather_ms = (time.perf_counter() - g0) * 1e3
         assert pool.shape == (ips, world * C, 1)
