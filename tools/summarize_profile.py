@@ -17,17 +17,16 @@ from collections import defaultdict
 
 
 def rows(pattern):
-    out = []
-    for f in glob.glob(pattern, recursive=True):
-        out += list(csv.DictReader(open(f)))
-    return out
+    """Rows of the NEWEST file matching the pattern (gpurun merges successive runs into one directory)."""
+    files = sorted(glob.glob(pattern, recursive=True), key=os.path.getmtime)
+    return list(csv.DictReader(open(files[-1]))) if files else []
 
 
 def main():
     src, tag, dst = sys.argv[1:4]
     build = sys.argv[4] if len(sys.argv) > 4 else "latest"
     os.makedirs(dst, exist_ok=True)
-    stats = glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True)[0]
+    stats = sorted(glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True), key=os.path.getmtime)[-1]
     shutil.copy(stats, os.path.join(dst, f"{tag}_{build}_kernel_stats.csv"))
     top = max(csv.DictReader(open(stats)), key=lambda r: float(r["TotalDurationNs"]))
     kern = top["Name"]
