@@ -31,32 +31,38 @@ struct Consts {
   int32_t nchunks;                // ceil((nout-1)/kc); 1 => tables stay resident in LDS
 };
 
-// per-lane proposal constants, hoisted out of the time loop (V_ref folded in where it multiplies)
+// Per-lane proposal constants, hoisted out of the time loop.  The integrator works on the rescaled state
+//   ms = mu / k'      (k' = 1e-2*10/Dc, RateStateModel.py:324)      x = theta / Dc
+// — a linear change of variables, so RK4 produces the same trajectory to rounding — because two
+// multiplications then drop out of every RHS evaluation: d(ms)/dt = V_l - v and d(theta)/dt = 1 - w x.
 struct Lane {
   double inv_dc;  // 1/Dc
-  double xs;      // V_ref/Dc: argument scale of the log, RateStateModel.py:336
-  double kprime;  // 1e-2*10/Dc, RateStateModel.py:324
-  double kpv;     // kprime*V_ref
-  double inv_a;   // 1/a
+  double kprime;  // k'
+  double kia;     // k'/a          : d(mu)/a = kia * d(ms)
+  double k1k;     // k1/k'         : radiation damping in ms units
   double via;     // V_ref/a
-  double b;
+  double bdc;     // b/Dc          : b/theta = bdc / x
   double boa;     // b/a
   double tc;      // -mu_ref/a
+  double hhd, hd, h6d;  // (h/2)/Dc, h/Dc, (h/6)/Dc : theta increments in x units
   double c_l1p;   // leading series coefficients kept in VGPRs (a VOP3 takes one SGPR source and the first Horner
   double c_em1;   //   term has two non-inline constants): log1p 1/7 (wide) or -1/6 (narrow); expm1 1/5040
 };
 
 __device__ __forceinline__ Lane make_lane(double dc, double a, double b, const Consts &K) {
   Lane L;
+  const double inv_a = 1.0 / a;
   L.inv_dc = 1.0 / dc;
-  L.xs = K.V_ref * L.inv_dc;
   L.kprime = (1e-2 * 10) / dc;
-  L.kpv = L.kprime * K.V_ref;
-  L.inv_a = 1.0 / a;
-  L.via = K.V_ref * L.inv_a;
-  L.b = b;
-  L.boa = b * L.inv_a;
-  L.tc = -K.mu_ref * L.inv_a;
+  L.kia = L.kprime * inv_a;
+  L.k1k = K.k1 / L.kprime;
+  L.via = K.V_ref * inv_a;
+  L.bdc = b * L.inv_dc;
+  L.boa = b * inv_a;
+  L.tc = -K.mu_ref * inv_a;
+  L.hhd = K.hh * L.inv_dc;
+  L.hd = K.h * L.inv_dc;
+  L.h6d = K.h6 * L.inv_dc;
   L.c_l1p = 1.0 / 7.0;
   L.c_em1 = 1.0 / 5040.0;
   asm volatile("" : "+v"(L.c_l1p), "+v"(L.c_em1));  // opaque: stays a register value, not re-materialised per step
@@ -68,41 +74,41 @@ __device__ __forceinline__ Lane make_lane(double dc, double a, double b, const C
 // Same quantities as the reference, regrouped so that every reciprocal is hoisted into Lane and
 // the slip rate appears only as w = v/V_ref = exp((mu-mu_ref)/a - (b/a) log(V_ref*theta/Dc)).
 // ---------------------------------------------------------------------------------------------
-// Integration state of one lane.  (w, rth) are the transcendental parts of the RHS at (mu, th):
-//   w = v/V_ref = exp((mu-mu_ref)/a - (b/a) log(V_ref*th/Dc)),   rth = 1/th.
+// Integration state of one lane: ms = mu/k', x = theta/Dc, V, and the transcendental parts of the RHS at
+// that point:  w = v/V_ref = exp(mu/a - mu_ref/a - (b/a) log(V_ref x)),   rx = 1/x.
 struct State {
-  double mu, th, V;
-  double w, rth;
+  double ms, x, V;
+  double w, rx;
 };
 
-// the part of the RHS after w = v/V_ref and 1/theta are known
+// the RHS once w and 1/x are known.  d0 = d(ms)/dt, d1 = d(theta)/dt (so dx = d1/Dc), d2 = dV/dt.
 template <bool DAMP>
-__device__ __forceinline__ void rhs_tail(double w, double rth, double th, double vl, const Lane &L,
+__device__ __forceinline__ void rhs_tail(double w, double rx, double x, double vl, const Lane &L,
                                          const Consts &K, double &d0, double &d1, double &d2) {
-  d1 = __builtin_fma(-w, th * L.inv_dc, 1.0);        // ageing law: 1 - v*theta/Dc
-  d0 = __builtin_fma(-L.kpv, w, L.kprime * vl);      // spring loading: k'(V_l - v)
-  const double bt = (L.b * d1) * rth;                // b/theta * dtheta/dt
+  d1 = __builtin_fma(-w, x, 1.0);                    // ageing law: 1 - v*theta/Dc
+  d0 = __builtin_fma(-K.V_ref, w, vl);               // spring loading / k':  V_l - v
+  const double bt = (L.bdc * d1) * rx;               // b/theta * dtheta/dt
   const double va = w * L.via;                       // v/a
-  d2 = va * (d0 - bt);
+  d2 = va * __builtin_fma(L.kprime, d0, -bt);        // v/a (dmu/dt - b/theta dtheta/dt), RateStateModel.py:346
   if (DAMP) {                                        // one fixed-point pass, RateStateModel.py:349-353
-    d0 = __builtin_fma(-K.k1, d2, d0);
-    d2 = va * (d0 - bt);
+    d0 = __builtin_fma(-L.k1k, d2, d0);
+    d2 = va * __builtin_fma(L.kprime, d0, -bt);
   }
 }
 
-// (w, 1/theta) by full evaluation
-__device__ __forceinline__ void eval_full(double mu, double th, const Lane &L, double &w, double &rth) {
+// (w, 1/x) by full evaluation
+__device__ __forceinline__ void eval_full(double ms, double x, const Lane &L, const Consts &K, double &w, double &rx) {
 #ifdef RSF_MATH_OCML
-  w = ::exp(__builtin_fma(-L.boa, ::log(th * L.xs), __builtin_fma(mu, L.inv_a, L.tc)));
-  rth = 1.0 / th;
+  w = ::exp(__builtin_fma(-L.boa, ::log(x * K.V_ref), __builtin_fma(ms, L.kia, L.tc)));
+  rx = 1.0 / x;
 #else
-  w = fm::exp(__builtin_fma(-L.boa, fm::log(th * L.xs), __builtin_fma(mu, L.inv_a, L.tc)));
-  rth = fm::rcp(th);
+  w = fm::exp(__builtin_fma(-L.boa, fm::log(x * K.V_ref), __builtin_fma(ms, L.kia, L.tc)));
+  rx = fm::rcp(x);
 #endif
 }
 
-// (w', 1/th') at (mu + dmu, th1 = th + dth) from (w, rth) at (mu, th).  With rho = dth/th and
-// dlt = dmu/a - (b/a) log1p(rho):   w' = w exp(dlt),   1/th' = (1/th)/(1 + rho),
+// (w', 1/x') at (ms + dms, x1 = x + dx) from (w, rx) at (ms, x).  With rho = dx/x (= dtheta/theta) and
+// dlt = dmu/a - (b/a) log1p(rho), dmu/a = kia*dms:   w' = w exp(dlt),   1/x' = (1/x)/(1 + rho),
 // by short series — the same function of (mu', th') to rounding inside the guard region:
 //   |dlt| < 2^-6 : expm1 to dlt^7/5040                      (next term < 9e-20)
 //   NARROW |rho| < 2^-9 : log1p to rho^6/6, 1/th' by a 2nd-order start + 1 Newton step (rho^6 < 2^-54)
@@ -113,9 +119,9 @@ struct Guard {
 };
 
 template <bool WIDE>
-__device__ __forceinline__ void eval_incr(double dmu, double dth, double th1, const Lane &L, double w0, double rth0,
+__device__ __forceinline__ void eval_incr(double dms, double dx, double th1, const Lane &L, double w0, double rth0,
                                           double &w, double &rth, Guard &g) {
-  const double rho = dth * rth0;
+  const double rho = dx * rth0;
   g.rho = __builtin_fmax(g.rho, __builtin_fabs(rho));
   double p;
   if (WIDE) {
@@ -128,7 +134,7 @@ __device__ __forceinline__ void eval_incr(double dmu, double dth, double th1, co
   p = fm::hfma(p, rho, 1.0 / 3.0);
   p = __builtin_fma(p, rho, -0.5);
   p = __builtin_fma(p, rho, 1.0);
-  const double dlt = __builtin_fma(-L.boa, p * rho, dmu * L.inv_a);
+  const double dlt = __builtin_fma(-L.boa, p * rho, dms * L.kia);
   g.dlt = __builtin_fmax(g.dlt, __builtin_fabs(dlt));
   double e = fm::hfma(L.c_em1, dlt, 1.0 / 720.0);
   e = fm::hfma(e, dlt, 1.0 / 120.0);
@@ -177,44 +183,44 @@ __device__ __forceinline__ void rk4_cold(State &s, double vl0, double vlm, doubl
     const double c = st == 0 ? 0.0 : (st == 3 ? K.h : K.hh);
     const double wgt = (st == 0 || st == 3) ? 1.0 : 2.0;
     const double vl = st == 0 ? vl0 : (st == 3 ? vl1 : vlm);
-    const double th1 = __builtin_fma(c, k1, s.th);
-    double w, rth, d0, d1, d2;
-    eval_full(__builtin_fma(c, k0, s.mu), th1, L, w, rth);
-    rhs_tail<DAMP>(w, rth, th1, vl, L, K, d0, d1, d2);
+    const double x1 = __builtin_fma(c * L.inv_dc, k1, s.x);
+    double w, rx, d0, d1, d2;
+    eval_full(__builtin_fma(c, k0, s.ms), x1, L, K, w, rx);
+    rhs_tail<DAMP>(w, rx, x1, vl, L, K, d0, d1, d2);
     s0 = __builtin_fma(wgt, d0, s0);
     s1 = __builtin_fma(wgt, d1, s1);
     s2 = __builtin_fma(wgt, d2, s2);
     k0 = d0;
     k1 = d1;
   }
-  s.mu = __builtin_fma(K.h6, s0, s.mu);
-  s.th = __builtin_fma(K.h6, s1, s.th);
+  s.ms = __builtin_fma(K.h6, s0, s.ms);
+  s.x = __builtin_fma(L.h6d, s1, s.x);
   s.V = __builtin_fma(K.h6, s2, s.V);
 }
 
 template <bool DAMP, bool WIDE>
 __device__ __forceinline__ void rk4_fast(State &s, double vl0, double vlm, double vl1, const Lane &L,
                                          const Consts &K, Guard &g) {
-  double a0, a1, a2, b0, b1, b2, c0, c1, c2, e0, e1, e2, w, rth;
-  rhs_tail<DAMP>(s.w, s.rth, s.th, vl0, L, K, a0, a1, a2);
-  double dth = K.hh * a1;
-  eval_incr<WIDE>(K.hh * a0, dth, s.th + dth, L, s.w, s.rth, w, rth, g);
-  rhs_tail<DAMP>(w, rth, s.th + dth, vlm, L, K, b0, b1, b2);
-  dth = K.hh * b1;
-  eval_incr<WIDE>(K.hh * b0, dth, s.th + dth, L, s.w, s.rth, w, rth, g);
-  rhs_tail<DAMP>(w, rth, s.th + dth, vlm, L, K, c0, c1, c2);
-  dth = K.h * c1;
-  eval_incr<WIDE>(K.h * c0, dth, s.th + dth, L, s.w, s.rth, w, rth, g);
-  rhs_tail<DAMP>(w, rth, s.th + dth, vl1, L, K, e0, e1, e2);
-  const double dmu = K.h6 * (a0 + 2.0 * b0 + 2.0 * c0 + e0);
-  dth = K.h6 * (a1 + 2.0 * b1 + 2.0 * c1 + e1);
-  const double th1 = s.th + dth;
-  eval_incr<WIDE>(dmu, dth, th1, L, s.w, s.rth, w, rth, g);
-  s.mu = s.mu + dmu;
-  s.th = th1;
+  double a0, a1, a2, b0, b1, b2, c0, c1, c2, e0, e1, e2, w, rx;
+  rhs_tail<DAMP>(s.w, s.rx, s.x, vl0, L, K, a0, a1, a2);
+  double dx = L.hhd * a1;
+  eval_incr<WIDE>(K.hh * a0, dx, s.x + dx, L, s.w, s.rx, w, rx, g);
+  rhs_tail<DAMP>(w, rx, s.x + dx, vlm, L, K, b0, b1, b2);
+  dx = L.hhd * b1;
+  eval_incr<WIDE>(K.hh * b0, dx, s.x + dx, L, s.w, s.rx, w, rx, g);
+  rhs_tail<DAMP>(w, rx, s.x + dx, vlm, L, K, c0, c1, c2);
+  dx = L.hd * c1;
+  eval_incr<WIDE>(K.h * c0, dx, s.x + dx, L, s.w, s.rx, w, rx, g);
+  rhs_tail<DAMP>(w, rx, s.x + dx, vl1, L, K, e0, e1, e2);
+  const double dms = K.h6 * (a0 + 2.0 * b0 + 2.0 * c0 + e0);
+  dx = L.h6d * (a1 + 2.0 * b1 + 2.0 * c1 + e1);
+  const double x1 = s.x + dx;
+  eval_incr<WIDE>(dms, dx, x1, L, s.w, s.rx, w, rx, g);
+  s.ms = s.ms + dms;
+  s.x = x1;
   s.V = s.V + K.h6 * (a2 + 2.0 * b2 + 2.0 * c2 + e2);
   s.w = w;
-  s.rth = rth;
+  s.rx = rx;
 }
 
 // advance one step; `resync` (wave-uniform, from the step index) asks for a full re-evaluation of (w, 1/th) first
@@ -225,24 +231,24 @@ __device__ __forceinline__ void rk4_step(State &s, bool resync, double vl0, doub
   rk4_cold<DAMP>(s, vl0, vlm, vl1, L, K);
   (void)resync;
 #else
-  if (resync) eval_full(s.mu, s.th, L, s.w, s.rth);
+  if (resync) eval_full(s.ms, s.x, L, K, s.w, s.rx);
   const State save = s;
   Guard g = {0.0, 0.0};
   rk4_fast<DAMP, true>(s, vl0, vlm, vl1, L, K, g);
   if (__builtin_expect(!guard_ok<true>(g), 0)) {  // an increment too large (or Inf; NaN passes through): cold path
     s = save;
     rk4_cold<DAMP>(s, vl0, vlm, vl1, L, K);
-    eval_full(s.mu, s.th, L, s.w, s.rth);
+    eval_full(s.ms, s.x, L, K, s.w, s.rx);
   }
 #endif
 }
 
 __device__ __forceinline__ State initial_state(double dc, const Lane &L, const Consts &K) {
   State s;
-  s.mu = K.mu0;                 // RateStateModel.py:367-377
-  s.th = dc / K.V_ref;
+  s.ms = K.mu0 / L.kprime;             // mu(0) = mu_t_zero, RateStateModel.py:367-377
+  s.x = (dc / K.V_ref) * L.inv_dc;     // theta(0) = Dc/V_ref
   s.V = K.V_ref;
-  eval_full(s.mu, s.th, L, s.w, s.rth);
+  eval_full(s.ms, s.x, L, K, s.w, s.rx);
   return s;
 }
 
@@ -281,7 +287,7 @@ __device__ __forceinline__ void integrate_pairs(const double *lds, const double 
   for (; kk + 2 <= kn; kk += 2) {
     const double *v = lds + 2 * kk;
     const double dd0 = ld[kk], dd1 = ld[kk + 1];
-    if ((kk & (RSF_RESYNC - 1)) == 0) eval_full(s.mu, s.th, L, s.w, s.rth);
+    if ((kk & (RSF_RESYNC - 1)) == 0) eval_full(s.ms, s.x, L, K, s.w, s.rx);
     const State save = s;
     Guard g = {0.0, 0.0};
     rk4_fast<DAMP, WIDE>(s, v[0], v[1], v[2], L, K, g);
@@ -292,7 +298,7 @@ __device__ __forceinline__ void integrate_pairs(const double *lds, const double 
       rk4_cold<DAMP>(s, v[0], v[1], v[2], L, K);
       vmid = s.V;
       rk4_cold<DAMP>(s, v[2], v[3], v[4], L, K);
-      eval_full(s.mu, s.th, L, s.w, s.rth);
+      eval_full(s.ms, s.x, L, K, s.w, s.rx);
     }
     const double ak0 = (vmid - save.V) * K.inv_dt, ak1 = (s.V - vmid) * K.inv_dt;  // RateStateModel.py:388
     if (WANT_ACC) {
@@ -309,7 +315,7 @@ __device__ __forceinline__ void integrate_pairs(const double *lds, const double 
     const double *v = lds + 2 * kk;
     const double vprev = s.V;
     rk4_cold<DAMP>(s, v[0], v[1], v[2], L, K);
-    eval_full(s.mu, s.th, L, s.w, s.rth);
+    eval_full(s.ms, s.x, L, K, s.w, s.rx);
     const double ak = (s.V - vprev) * K.inv_dt;
     if (WANT_ACC) acc_out[(int64_t)(k0 + kk) * stride] = ak;
     if (WANT_SSQ) {
