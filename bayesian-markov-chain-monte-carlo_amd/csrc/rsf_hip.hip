@@ -23,6 +23,7 @@
 
 #include "../../include/rsf_abi.h"
 #include "rsf_device.h"
+#include "rsf_device_f32.h"
 
 using rsf::Consts;
 
@@ -50,7 +51,7 @@ constexpr size_t kLdsBudget = 32 * 1024; // per workgroup; 4 workgroups/CU still
 // ---------------------------------------------------------------------------------------------
 // kernels
 // ---------------------------------------------------------------------------------------------
-template <bool DAMP, bool WANT_SSQ, bool WANT_ACC>
+template <bool DAMP, bool WANT_SSQ, bool WANT_ACC, bool F32>
 __global__ void __launch_bounds__(kMaxBlock)
 forward_kernel(Consts K, int64_t n, const double *__restrict__ dc, const double *__restrict__ a,
                const double *__restrict__ b, double *__restrict__ ssq_out, double *__restrict__ acc_out) {
@@ -62,11 +63,21 @@ forward_kernel(Consts K, int64_t n, const double *__restrict__ dc, const double 
   const double bi = (active && b) ? b[i] : K.b_def;
   double *acc_i = WANT_ACC ? acc_out + i : nullptr;
   double ssq;
-  if (K.nchunks == 1) {
-    rsf::stage_chunk(lds, K, 1, K.nout - 1);
-    ssq = rsf::solve<DAMP, WANT_SSQ, WANT_ACC, true>(lds, K, active, dci, ai, bi, acc_i, n);
+  if constexpr (F32) {
+    float *lds32 = reinterpret_cast<float *>(lds);
+    if (K.nchunks == 1) {
+      rsf::f32::stage_chunk32(lds32, K, 1, K.nout - 1);
+      ssq = rsf::f32::solve32<DAMP, WANT_SSQ, WANT_ACC, true>(lds32, K, active, dci, ai, bi, acc_i, n);
+    } else {
+      ssq = rsf::f32::solve32<DAMP, WANT_SSQ, WANT_ACC, false>(lds32, K, active, dci, ai, bi, acc_i, n);
+    }
   } else {
-    ssq = rsf::solve<DAMP, WANT_SSQ, WANT_ACC, false>(lds, K, active, dci, ai, bi, acc_i, n);
+    if (K.nchunks == 1) {
+      rsf::stage_chunk(lds, K, 1, K.nout - 1);
+      ssq = rsf::solve<DAMP, WANT_SSQ, WANT_ACC, true>(lds, K, active, dci, ai, bi, acc_i, n);
+    } else {
+      ssq = rsf::solve<DAMP, WANT_SSQ, WANT_ACC, false>(lds, K, active, dci, ai, bi, acc_i, n);
+    }
   }
   if (WANT_SSQ && active) ssq_out[i] = ssq;
 }
@@ -148,6 +159,19 @@ __global__ void __launch_bounds__(kMaxBlock) init_kernel(Consts K, InitArgs A) {
   }
 }
 
+// float32 mode: the sampler compares sums of squares from float32 solves, so the initial SSq (computed by the
+// float64 init kernel together with the float64-only sensitivities) is replaced by its float32 value.
+template <int D, bool DAMP>
+__global__ void __launch_bounds__(kMaxBlock) ssq32_kernel(Consts K, int64_t C, const double *q, double *ssq) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool active = i < C;
+  const double dc = active ? q[i * D] : 1.0;
+  const double a = (active && D == 3) ? q[i * D + 1] : K.a_def, b = (active && D == 3) ? q[i * D + 2] : K.b_def;
+  const double s = rsf::f32::solve32<DAMP, true, false, false>(reinterpret_cast<float *>(lds), K, active, dc, a, b, nullptr, 0);
+  if (active) ssq[i] = s;
+}
+
 struct McmcArgs {
   int64_t C, chain_offset, n_iters, iter_base;
   uint64_t seed;
@@ -163,7 +187,7 @@ struct McmcArgs {
   uint8_t *ta;
 };
 
-template <int D, bool DAMP, bool REPLAY>
+template <int D, bool DAMP, bool REPLAY, bool F32>
 __global__ void __launch_bounds__(kMaxBlock) mcmc_kernel(Consts K, McmcArgs A) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -196,7 +220,11 @@ __global__ void __launch_bounds__(kMaxBlock) mcmc_kernel(Consts K, McmcArgs A) {
   }
   uint32_t n_acc = 0, n_eval = 0, n_nonfinite = 0;
 
-  if (resident) rsf::stage_chunk(lds, K, 1, K.nout - 1);
+  float *lds32 = reinterpret_cast<float *>(lds);
+  if (resident) {
+    if constexpr (F32) rsf::f32::stage_chunk32(lds32, K, 1, K.nout - 1);
+    else rsf::stage_chunk(lds, K, 1, K.nout - 1);
+  }
 
   for (int64_t n = 0; n < A.n_iters; ++n) {
     const uint32_t it = (uint32_t)(A.iter_base + n);
@@ -231,10 +259,18 @@ __global__ void __launch_bounds__(kMaxBlock) mcmc_kernel(Consts K, McmcArgs A) {
     // ---- likelihood: forward solve only for in-bounds proposals, MCMC.py:322-324 ----
     const double an = D == 3 ? qn[1] : K.a_def, bn = D == 3 ? qn[2] : K.b_def;
     double ssqn = 0.0;
-    if (resident) {
-      if (inb) ssqn = rsf::solve<DAMP, true, false, true>(lds, K, true, qn[0], an, bn, nullptr, 0);
+    if constexpr (F32) {
+      if (resident) {
+        if (inb) ssqn = rsf::f32::solve32<DAMP, true, false, true>(lds32, K, true, qn[0], an, bn, nullptr, 0);
+      } else {
+        ssqn = rsf::f32::solve32<DAMP, true, false, false>(lds32, K, inb, qn[0], an, bn, nullptr, 0);
+      }
     } else {
-      ssqn = rsf::solve<DAMP, true, false, false>(lds, K, inb, qn[0], an, bn, nullptr, 0);
+      if (resident) {
+        if (inb) ssqn = rsf::solve<DAMP, true, false, true>(lds, K, true, qn[0], an, bn, nullptr, 0);
+      } else {
+        ssqn = rsf::solve<DAMP, true, false, false>(lds, K, inb, qn[0], an, bn, nullptr, 0);
+      }
     }
     // ---- accept / reject, MCMC.py:327-333 ----
     bool accept = false;
@@ -465,14 +501,21 @@ Consts make_consts(const rsf_ctx *c, const double *data) {
 
 unsigned grid_for(const rsf_ctx *c, int64_t n) { return (unsigned)((n + c->block - 1) / c->block); }
 
-template <int D, bool DAMP>
+template <int D, bool DAMP, bool F32>
 int launch_mcmc(rsf_ctx *c, const Consts &K, const McmcArgs &A, bool replay) {
   const dim3 grid(grid_for(c, A.C)), block(c->block);
   if (replay)
-    hipLaunchKernelGGL((mcmc_kernel<D, DAMP, true>), grid, block, c->lds_bytes, c->stream, K, A);
+    hipLaunchKernelGGL((mcmc_kernel<D, DAMP, true, F32>), grid, block, c->lds_bytes, c->stream, K, A);
   else
-    hipLaunchKernelGGL((mcmc_kernel<D, DAMP, false>), grid, block, c->lds_bytes, c->stream, K, A);
+    hipLaunchKernelGGL((mcmc_kernel<D, DAMP, false, F32>), grid, block, c->lds_bytes, c->stream, K, A);
   return RSF_OK;
+}
+
+template <int D>
+int launch_mcmc_d(rsf_ctx *c, const Consts &K, const McmcArgs &A, bool replay) {
+  const bool damp = c->m.flags & RSF_FLAG_RADIATION_DAMPING, f32 = c->m.flags & RSF_FLAG_FP32_SOLVE;
+  if (f32) return damp ? launch_mcmc<D, true, true>(c, K, A, replay) : launch_mcmc<D, false, true>(c, K, A, replay);
+  return damp ? launch_mcmc<D, true, false>(c, K, A, replay) : launch_mcmc<D, false, false>(c, K, A, replay);
 }
 
 int run_mcmc(rsf_ctx *c, int64_t n_iters, const double *z, const double *u, const double *g, double *tq,
@@ -505,9 +548,7 @@ int run_mcmc(rsf_ctx *c, int64_t n_iters, const double *z, const double *u, cons
   A.z = (const double *)dz; A.u = (const double *)du; A.g = (const double *)dg;
   A.tq = (double *)dtq; A.ts = (double *)dts; A.ta = (uint8_t *)dta;
   const Consts K = make_consts(c, (const double *)c->data.p);
-  const bool damp = c->m.flags & RSF_FLAG_RADIATION_DAMPING;
-  if (d == 1) rc = damp ? launch_mcmc<1, true>(c, K, A, replay) : launch_mcmc<1, false>(c, K, A, replay);
-  else rc = damp ? launch_mcmc<3, true>(c, K, A, replay) : launch_mcmc<3, false>(c, K, A, replay);
+  rc = d == 1 ? launch_mcmc_d<1>(c, K, A, replay) : launch_mcmc_d<3>(c, K, A, replay);
   if (rc) return rc;
   if ((rc = copy_back(c, 3, tq, rows * d * sizeof(double)))) return rc;
   if ((rc = copy_back(c, 4, ts, rows * sizeof(double)))) return rc;
@@ -651,9 +692,16 @@ int rsf_forward_batch(rsf_ctx *c, int64_t n, const double *dc, const double *a, 
   const Consts K = make_consts(c, (const double *)ddata);
   const dim3 grid(grid_for(c, n)), block(c->block);
   const bool damp = c->m.flags & RSF_FLAG_RADIATION_DAMPING;
-#define RSF_LAUNCH_FWD(DAMP, SSQ, ACC)                                                                 \
-  hipLaunchKernelGGL((forward_kernel<DAMP, SSQ, ACC>), grid, block, c->lds_bytes, c->stream, K, n,     \
-                     (const double *)ddc, (const double *)da, (const double *)db, (double *)dssq, (double *)dacc)
+#define RSF_LAUNCH_FWD(DAMP, SSQ, ACC)                                                                      \
+  do {                                                                                                      \
+    if (f32)                                                                                                \
+      hipLaunchKernelGGL((forward_kernel<DAMP, SSQ, ACC, true>), grid, block, c->lds_bytes, c->stream, K, n, \
+                         (const double *)ddc, (const double *)da, (const double *)db, (double *)dssq, (double *)dacc); \
+    else                                                                                                    \
+      hipLaunchKernelGGL((forward_kernel<DAMP, SSQ, ACC, false>), grid, block, c->lds_bytes, c->stream, K, n, \
+                         (const double *)ddc, (const double *)da, (const double *)db, (double *)dssq, (double *)dacc); \
+  } while (0)
+  const bool f32 = c->m.flags & RSF_FLAG_FP32_SOLVE;
   const int sel = (damp ? 4 : 0) | (ssq_out ? 2 : 0) | (acc_out ? 1 : 0);
   switch (sel) {
     case 0: case 4: break;  // nothing requested
@@ -719,6 +767,15 @@ int rsf_mcmc_init(rsf_ctx *c, const rsf_mcmc_config *cfg, const double *q0, cons
   } else {
     if (damp) hipLaunchKernelGGL((init_kernel<3, true>), grid, block, c->lds_bytes, c->stream, K, A);
     else hipLaunchKernelGGL((init_kernel<3, false>), grid, block, c->lds_bytes, c->stream, K, A);
+  }
+  if (c->m.flags & RSF_FLAG_FP32_SOLVE) {
+    if (d == 1) {
+      if (damp) hipLaunchKernelGGL((ssq32_kernel<1, true>), grid, block, c->lds_bytes, c->stream, K, C, A.q0, A.ssq);
+      else hipLaunchKernelGGL((ssq32_kernel<1, false>), grid, block, c->lds_bytes, c->stream, K, C, A.q0, A.ssq);
+    } else {
+      if (damp) hipLaunchKernelGGL((ssq32_kernel<3, true>), grid, block, c->lds_bytes, c->stream, K, C, A.q0, A.ssq);
+      else hipLaunchKernelGGL((ssq32_kernel<3, false>), grid, block, c->lds_bytes, c->stream, K, C, A.q0, A.ssq);
+    }
   }
   c->mc = *cfg;
   c->iters_done = 0;

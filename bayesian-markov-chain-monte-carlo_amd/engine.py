@@ -19,6 +19,11 @@ def _model_struct(model, substeps):
     m = _abi.Model()
     m.size = ctypes.sizeof(_abi.Model)
     m.flags = _abi.FLAG_RADIATION_DAMPING if getattr(model, "RadiationDamping", True) else 0
+    precision = getattr(model, "precision", "float64")
+    if precision not in ("float64", "float32"):
+        raise ValueError(f"precision must be 'float64' or 'float32', not {precision!r}")
+    if precision == "float32":
+        m.flags |= _abi.FLAG_FP32_SOLVE
     m.nsteps = int(model.num_tsteps)
     m.substeps = int(substeps)
     m.t_start, m.t_final = float(model.t_start), float(model.t_final)

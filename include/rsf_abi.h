@@ -59,6 +59,8 @@ extern "C" {
 
 /* rsf_model.flags */
 #define RSF_FLAG_RADIATION_DAMPING 1u /* RateStateModel.RadiationDamping, RateStateModel.py:183 */
+#define RSF_FLAG_FP32_SOLVE 2u        /* integrate the ODE in float32 (BASELINE config 5 tolerance sweep); all
+                                         interface arrays, the SSq accumulator and the sampler logic stay float64 */
 
 /* rsf_mcmc_config.adapt_mode (MCMC.py:162-204, 523-527) */
 #define RSF_ADAPT_NONE 0           /* list prior: adaptation raises and is swallowed => never adapts */

@@ -179,6 +179,9 @@ int rsf_set_model(rsf_ctx *c, const rsf_model *m) {
   if (m->size != sizeof(rsf_model)) return fail(RSF_ERR_INVALID, "rsf_set_model: struct size mismatch");
   if (m->nsteps < 2 || m->substeps < 1 || !(m->t_final > m->t_start))
     return fail(RSF_ERR_INVALID, "rsf_set_model: need nsteps >= 2, substeps >= 1, t_final > t_start");
+  if (m->flags & RSF_FLAG_FP32_SOLVE)
+    return fail(RSF_ERR_UNSUPPORTED, "rsf_set_model: the CPU restatement is float64 only (the float32 solve is "
+                                     "checked against the float64 GPU path within the sweep tolerance)");
   c->m = *m;
   c->delta_t = (m->t_final - m->t_start) / m->nsteps;                   /* RateStateModel.py:176 */
   c->nout = (int32_t)floor((m->t_final - m->t_start) / c->delta_t);     /* RateStateModel.py:358 */

@@ -39,6 +39,7 @@ class ModelSpec:
         self.mu_t_zero = MU_REF
         self.RadiationDamping = True
         self.substeps = substeps
+        self.precision = "float64"
 
     @property
     def nout(self):
