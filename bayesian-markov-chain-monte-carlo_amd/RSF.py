@@ -123,6 +123,38 @@ class RSF:
         self.posteriors[float(dc)] = qparams
         self.plot_dist(qparams, dc)
 
+    def inference_batched(self, nsamples, chains_per_dc=256, seed=0, mem="device", device=-1, adapt_mode=None):
+        """Additive throughput path: the whole dc_list sweep as ONE launch per block of iterations — every
+        true Dc is an observation group with `chains_per_dc` independent chains (Philox variates on device).
+        Returns {dc: PosteriorPool} of the post-burn-in draws (nburn = int(nsamples/2) like MCMC)."""
+        from .engine import Engine
+        from .MCMC import PosteriorPool
+
+        n, G = self.model.num_tsteps, len(self.dc_list)
+        data = np.ascontiguousarray(np.asarray(self.data, dtype=np.float64).reshape(G, n))
+        probe = MCMC(self.model, data[0], self.dc_list[0], self.qpriors, self.qstart, nsamples=nsamples)
+        nburn = probe.nburn
+        C = G * int(chains_per_dc)
+        eng = Engine(mem=mem, device=device)
+        try:
+            eng.set_model(self.model, getattr(self.model, "substeps", 1))
+            eng.mcmc_init(np.full((C, 1), float(self.qstart)), data, probe.qstart_limits[:, 0], probe.qstart_limits[:, 1],
+                          seed=seed, n0=probe.n0, prior_len=len(self.qpriors), adapt_mode=adapt_mode or probe._adapt_mode(),
+                          adapt_interval=probe.adapt_interval)
+            tq, ts, ta = eng.mcmc_run(nsamples)
+            eng.sync()
+            tq, ts, ta = (np.asarray(x.cpu() if hasattr(x, "cpu") else x) for x in (tq, ts, ta))
+        finally:
+            eng.close()
+        out, first = {}, max(nburn - 1, 0)
+        for g, dc in enumerate(self.dc_list):
+            sl = slice(g * chains_per_dc, (g + 1) * chains_per_dc)
+            acc = int(ta[:, sl].sum())
+            out[float(dc)] = PosteriorPool(tq[first:, sl], ts[first:, sl], acc / (nsamples * chains_per_dc),
+                                           dict(accepted=acc), nburn)
+        self.posteriors = {dc: pool.pooled() for dc, pool in out.items()}
+        return out
+
     @measure_execution_time
     def inference(self, nsamples):
         data = self.prepare_data(self.data)

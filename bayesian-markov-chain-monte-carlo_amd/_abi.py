@@ -70,7 +70,7 @@ class McmcConfig(ctypes.Structure):
         ("prior_len", c_int32),
         ("adapt_mode", c_int32),
         ("adapt_interval", c_int32),
-        ("reserved", c_int32),
+        ("n_groups", c_int32),
         ("fd_rel_step", c_double),
         ("lo", c_double * MAX_PARAMS),
         ("hi", c_double * MAX_PARAMS),

@@ -24,12 +24,18 @@ struct Consts {
   double h, hh, h6;               // RK4 step, h/2, h/6
   double inv_dt;                  // 1 / delta_t
   const double *vl;               // V_l at stage times t_start + j*h/2, j = 0 .. 2*S*(nout-1)
-  const double *data;             // observation [nout] or nullptr
+  const double *data;             // observation [nout] (of this workgroup's chain group) or nullptr
+  int64_t group_chains;           // chains per observation group (0: one series for all)
   int32_t nout;                   // output samples (RateStateModel.py:358)
   int32_t S;                      // RK4 steps per output interval
   int32_t kc;                     // output intervals per LDS chunk
   int32_t nchunks;                // ceil((nout-1)/kc); 1 => tables stay resident in LDS
 };
+
+// select the observation series of this workgroup (all its chains belong to one group)
+__device__ __forceinline__ void select_group(Consts &K) {
+  if (K.group_chains > 0) K.data += ((int64_t)blockIdx.x * blockDim.x / K.group_chains) * K.nout;
+}
 
 // Per-lane proposal constants, hoisted out of the time loop.  The integrator works on the rescaled state
 //   ms = mu / k'      (k' = 1e-2*10/Dc, RateStateModel.py:324)      x = theta / Dc

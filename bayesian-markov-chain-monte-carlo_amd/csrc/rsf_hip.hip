@@ -95,6 +95,7 @@ struct InitArgs {
 template <int D, bool DAMP>
 __global__ void __launch_bounds__(kMaxBlock) init_kernel(Consts K, InitArgs A) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
+  rsf::select_group(K);
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const bool active = i < A.C;
   double p0[3] = {1.0, K.a_def, K.b_def};
@@ -164,6 +165,7 @@ __global__ void __launch_bounds__(kMaxBlock) init_kernel(Consts K, InitArgs A) {
 template <int D, bool DAMP>
 __global__ void __launch_bounds__(kMaxBlock) ssq32_kernel(Consts K, int64_t C, const double *q, double *ssq) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
+  rsf::select_group(K);
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const bool active = i < C;
   const double dc = active ? q[i * D] : 1.0;
@@ -190,6 +192,7 @@ struct McmcArgs {
 template <int D, bool DAMP, bool REPLAY, bool F32>
 __global__ void __launch_bounds__(kMaxBlock) mcmc_kernel(Consts K, McmcArgs A) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
+  rsf::select_group(K);
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const bool valid = i < A.C;
   const uint64_t gid = (uint64_t)(A.chain_offset + i);  // RNG is keyed by the GLOBAL chain id
@@ -430,6 +433,7 @@ struct rsf_ctx {
   bool have_chains = false;
   rsf_mcmc_config mc{};
   DevBuf data, q, ssq, std2, V, wref, wsum, wsq, wn, stats;
+  int64_t group_chains = 0;  // chains per observation group (0: one series)
   int64_t iters_done = 0;
   // staging for RSF_MEM_HOST callers
   DevBuf stage[8];
@@ -496,6 +500,7 @@ Consts make_consts(const rsf_ctx *c, const double *data) {
   K.vl = (const double *)c->vl.p;
   K.data = data;
   K.nout = c->nout; K.S = c->m.substeps; K.kc = c->kc; K.nchunks = c->nchunks;
+  K.group_chains = 0;
   return K;
 }
 
@@ -547,7 +552,8 @@ int run_mcmc(rsf_ctx *c, int64_t n_iters, const double *z, const double *u, cons
   if ((rc = stage_out(c, 5, ta, rows, &dta))) return rc;
   A.z = (const double *)dz; A.u = (const double *)du; A.g = (const double *)dg;
   A.tq = (double *)dtq; A.ts = (double *)dts; A.ta = (uint8_t *)dta;
-  const Consts K = make_consts(c, (const double *)c->data.p);
+  Consts K = make_consts(c, (const double *)c->data.p);
+  K.group_chains = c->group_chains;
   rc = d == 1 ? launch_mcmc_d<1>(c, K, A, replay) : launch_mcmc_d<3>(c, K, A, replay);
   if (rc) return rc;
   if ((rc = copy_back(c, 3, tq, rows * d * sizeof(double)))) return rc;
@@ -728,13 +734,17 @@ int rsf_mcmc_init(rsf_ctx *c, const rsf_mcmc_config *cfg, const double *q0, cons
     return fail(RSF_ERR_UNSUPPORTED, "rsf_mcmc_init: reference_dict adaptation is defined for 1 parameter only");
   if (cfg->adapt_mode < 0 || cfg->adapt_mode > RSF_ADAPT_AM || (cfg->adapt_mode && cfg->adapt_interval < 2))
     return fail(RSF_ERR_INVALID, "rsf_mcmc_init: bad adapt_mode / adapt_interval");
+  const int G = cfg->n_groups > 1 ? cfg->n_groups : 1;
+  if (cfg->n_groups < 0 || cfg->n_chains % G || (G > 1 && (cfg->n_chains / G) % c->block))
+    return fail(RSF_ERR_INVALID, "rsf_mcmc_init: n_chains/n_groups must be a whole multiple of the workgroup size (%d)", c->block);
   DeviceGuard guard(c->device);
   if (!guard.ok) return fail(RSF_ERR_DEVICE, "rsf_mcmc_init: cannot select device %d", c->device);
   const int d = cfg->n_params;
   const int64_t C = cfg->n_chains;
   const size_t cb = (size_t)C * sizeof(double);
+  const size_t data_bytes = (size_t)G * (size_t)c->nout * sizeof(double);
   int rc;
-  if ((rc = ensure(c->data, (size_t)c->nout * sizeof(double)))) return rc;
+  if ((rc = ensure(c->data, data_bytes))) return rc;
   if ((rc = ensure(c->q, cb * d))) return rc;
   if ((rc = ensure(c->ssq, cb))) return rc;
   if ((rc = ensure(c->std2, cb))) return rc;
@@ -745,7 +755,7 @@ int rsf_mcmc_init(rsf_ctx *c, const rsf_mcmc_config *cfg, const double *q0, cons
   if ((rc = ensure(c->wn, (size_t)C * sizeof(int32_t)))) return rc;
   if ((rc = ensure(c->stats, 3 * sizeof(unsigned long long)))) return rc;
   const hipMemcpyKind kind = host_mem(c) ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
-  HIP_TRY(hipMemcpyAsync(c->data.p, data, (size_t)c->nout * sizeof(double), kind, c->stream));
+  HIP_TRY(hipMemcpyAsync(c->data.p, data, data_bytes, kind, c->stream));
   HIP_TRY(hipMemcpyAsync(c->q.p, q0, cb * d, kind, c->stream));
   HIP_TRY(hipMemcpyAsync(c->wref.p, q0, cb * d, kind, c->stream));
   HIP_TRY(hipMemsetAsync(c->wsum.p, 0, cb * d, c->stream));
@@ -758,7 +768,9 @@ int rsf_mcmc_init(rsf_ctx *c, const rsf_mcmc_config *cfg, const double *q0, cons
   A.inv_dof = 1.0 / (double)(c->nout - (cfg->prior_len ? cfg->prior_len : d));
   A.q0 = (const double *)c->q.p;
   A.ssq = (double *)c->ssq.p; A.std2 = (double *)c->std2.p; A.V = (double *)c->V.p;
-  const Consts K = make_consts(c, (const double *)c->data.p);
+  c->group_chains = G > 1 ? C / G : 0;
+  Consts K = make_consts(c, (const double *)c->data.p);
+  K.group_chains = c->group_chains;
   const dim3 grid(grid_for(c, C)), block(c->block);
   const bool damp = c->m.flags & RSF_FLAG_RADIATION_DAMPING;
   if (d == 1) {

@@ -135,15 +135,18 @@ class Engine:
             q0 = q0.reshape(-1, 1)
         C, d = int(q0.shape[0]), int(q0.shape[1])
         data = self._in(data)
-        if int(data.shape[0]) != self.nout:
-            raise ValueError(f"data has {int(data.shape[0])} entries, the model produces {self.nout}")
+        n_groups = int(data.shape[0]) if data.ndim == 2 else 1  # (G, nout): one observation series per chain group
+        if int(data.shape[-1]) != self.nout:
+            raise ValueError(f"data has {int(data.shape[-1])} entries per series, the model produces {self.nout}")
+        if C % n_groups:
+            raise ValueError(f"{C} chains cannot be split evenly over {n_groups} observation groups")
         lo, hi = np.broadcast_to(np.asarray(lo, dtype=np.float64), (d,)), np.broadcast_to(np.asarray(hi, dtype=np.float64), (d,))
         cfg = _abi.McmcConfig()
         cfg.size = ctypes.sizeof(_abi.McmcConfig)
         cfg.n_params, cfg.n_chains, cfg.chain_offset = d, C, int(chain_offset)
         cfg.seed, cfg.n0, cfg.prior_len = int(seed), float(n0), int(prior_len)
         cfg.adapt_mode = _abi.ADAPT_MODES[adapt_mode] if isinstance(adapt_mode, str) else int(adapt_mode)
-        cfg.adapt_interval, cfg.fd_rel_step = int(adapt_interval), float(fd_rel_step)
+        cfg.adapt_interval, cfg.fd_rel_step, cfg.n_groups = int(adapt_interval), float(fd_rel_step), n_groups
         for p in range(d):
             cfg.lo[p], cfg.hi[p] = float(lo[p]), float(hi[p])
         _abi.check(self.lib, self.lib.rsf_mcmc_init(self._ctx, ctypes.byref(cfg), self._ptr(q0), self._ptr(data)))

@@ -76,7 +76,7 @@ typedef struct rsf_config {
   uint32_t version;       /* = RSF_ABI_VERSION */
   int32_t device;         /* HIP device ordinal; -1 = current device */
   int32_t mem_space;      /* RSF_MEM_HOST or RSF_MEM_DEVICE for every array argument */
-  void *stream;           /* hipStream_t to launch on; NULL = a ctx-owned stream */
+  void *stream;           /* hipStream_t to launch on; NULL = the device's default stream */
   uint32_t block_threads; /* workgroup size (multiple of 64); 0 = default */
   uint32_t cpu_threads;   /* oracle library only: OpenMP threads, 0 = all */
 } rsf_config;
@@ -107,7 +107,8 @@ typedef struct rsf_mcmc_config {
   int32_t prior_len;      /* len(qpriors) quirk in std2[0] divisor, MCMC.py:261: 3 list / 2 dict; 0 => d */
   int32_t adapt_mode;     /* RSF_ADAPT_* */
   int32_t adapt_interval; /* MCMC.adapt_interval, default 10 */
-  int32_t reserved;
+  int32_t n_groups;       /* observation series: 0/1 = one shared by all chains; G > 1 = data is [G][nout] and
+                             chain i uses series i / (n_chains/G)  (RSF's dc_list sweep, RSF.py:874-882, in one launch) */
   double fd_rel_step;     /* 1e-6, MCMC.py:251 */
   double lo[RSF_MAX_PARAMS]; /* strict box prior, MCMC.py:318-320 */
   double hi[RSF_MAX_PARAMS];
@@ -149,8 +150,9 @@ int rsf_forward_batch(rsf_ctx *ctx, int64_t n_lanes, const double *dc, const dou
  * per chain: std2_0 = SSq(q0)/(nout - prior_len); Vstart = std2_0 * (X^T X)^-1 with X the
  * forward-difference sensitivity (perturbed-Dc denominator quirk kept, MCMC.py:251,264).
  * For d == 3 the sensitivity is taken per parameter (extension).
- *   q0[C][d]     start point per chain
- *   data[nout]   observation shared by all chains of this ctx (kept by the ctx) */
+ *   q0[C][d]              start point per chain
+ *   data[n_groups][nout]  observation series (kept by the ctx); n_chains must be a multiple of n_groups and,
+ *                         in the HIP library, n_chains/n_groups a multiple of the workgroup size */
 int rsf_mcmc_init(rsf_ctx *ctx, const rsf_mcmc_config *cfg, const double *q0, const double *data);
 
 /* Read / overwrite the per-chain sampler state.  Any pointer may be NULL.

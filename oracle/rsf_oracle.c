@@ -119,7 +119,8 @@ struct rsf_ctx {
   /* sampler */
   int have_chains;
   rsf_mcmc_config mc;
-  double *data;                 /* [nout] */
+  double *data;                 /* [n_groups][nout] */
+  int32_t n_groups;
   double *q, *ssq, *std2, *V;   /* [C][d], [C], [C], [C][d][d] */
   double *wref, *wsum, *wsq;    /* adaptation window: shift [C][d], sums [C][d], [C][d][d] */
   int32_t *wn;                  /* [C] samples in window */
@@ -271,9 +272,14 @@ int rsf_forward_batch(rsf_ctx *c, int64_t n, const double *dc, const double *a, 
 /* ------------------------------------------------------------------------------------ */
 /* sampler                                                                                */
 /* ------------------------------------------------------------------------------------ */
-static double ssq_of(const rsf_ctx *c, const double *q, int d) {
+/* observation series of local chain i (RSF.py:874-882: one series per true Dc) */
+static const double *data_of(const rsf_ctx *c, int64_t i) {
+  return c->data + (i / (c->mc.n_chains / c->n_groups)) * (int64_t)c->nout;
+}
+
+static double ssq_of(const rsf_ctx *c, int64_t i, const double *q, int d) {
   double a = d == 3 ? q[1] : c->m.a, b = d == 3 ? q[2] : c->m.b;
-  return solve(c, q[0], a, b, c->data, NULL, 0);
+  return solve(c, q[0], a, b, data_of(c, i), NULL, 0);
 }
 
 /* lower Cholesky factor of a d x d covariance; a failed pivot zeroes that column. */
@@ -316,12 +322,15 @@ int rsf_mcmc_init(rsf_ctx *c, const rsf_mcmc_config *cfg, const double *q0, cons
     return fail(RSF_ERR_UNSUPPORTED, "rsf_mcmc_init: reference_dict adaptation is defined for 1 parameter only");
   if (cfg->adapt_mode < 0 || cfg->adapt_mode > RSF_ADAPT_AM || (cfg->adapt_mode && cfg->adapt_interval < 2))
     return fail(RSF_ERR_INVALID, "rsf_mcmc_init: bad adapt_mode / adapt_interval");
+  if (cfg->n_groups < 0 || (cfg->n_groups > 1 && cfg->n_chains % cfg->n_groups))
+    return fail(RSF_ERR_INVALID, "rsf_mcmc_init: n_chains must be a multiple of n_groups");
   free_chains(c);
   c->mc = *cfg;
+  c->n_groups = cfg->n_groups > 1 ? cfg->n_groups : 1;
   const int d = cfg->n_params;
   const int64_t C = cfg->n_chains;
   const int32_t N = c->nout;
-  c->data = (double *)malloc(sizeof(double) * N);
+  c->data = (double *)malloc(sizeof(double) * N * c->n_groups);
   c->q = (double *)malloc(sizeof(double) * C * d);
   c->ssq = (double *)malloc(sizeof(double) * C);
   c->std2 = (double *)malloc(sizeof(double) * C);
@@ -334,7 +343,7 @@ int rsf_mcmc_init(rsf_ctx *c, const rsf_mcmc_config *cfg, const double *q0, cons
     free_chains(c);
     return fail(RSF_ERR_NOMEM, "rsf_mcmc_init: out of memory");
   }
-  memcpy(c->data, data, sizeof(double) * N);
+  memcpy(c->data, data, sizeof(double) * N * c->n_groups);
   memcpy(c->q, q0, sizeof(double) * C * d);
   memcpy(c->wref, q0, sizeof(double) * C * d);
   const int plen = cfg->prior_len ? cfg->prior_len : d;
@@ -349,7 +358,7 @@ int rsf_mcmc_init(rsf_ctx *c, const rsf_mcmc_config *cfg, const double *q0, cons
     for (int64_t i = 0; i < C; ++i) {
       const double *q = c->q + i * d;
       double a = d == 3 ? q[1] : c->m.a, b = d == 3 ? q[2] : c->m.b;
-      double s0 = solve(c, q[0], a, b, c->data, acc0, 1);    /* MCMC.py:245-246, 468 */
+      double s0 = solve(c, q[0], a, b, data_of(c, i), acc0, 1);    /* MCMC.py:245-246, 468 */
       double qp[3], XtX[9], Xi[9];
       for (int p = 0; p < d; ++p) {                          /* MCMC.py:251-252 */
         double pq[3] = {q[0], a, b};
@@ -441,7 +450,7 @@ static void run_chain(rsf_ctx *c, int64_t i, int64_t n_iters, const double *zs, 
     int inb = 1, accept = 0;
     for (int p = 0; p < d; ++p) inb = inb && (qn[p] > mc->lo[p]) && (qn[p] < mc->hi[p]);
     if (inb) {
-      double ssqn = ssq_of(c, qn, d);
+      double ssqn = ssq_of(c, i, qn, d);
       double u;
       if (us) u = us[n * C + i];
       else { uint32_t w[4]; draw_words(mc->seed, gid, it, SLOT_U, w); u = u53(w[0], w[1]); }

@@ -63,3 +63,19 @@ def test_main_entry_runs_on_the_gpu(pkg, tmp_path, monkeypatch):
     assert out.getvalue().count("--- Dc is") == 5
     for dc, q in problem.posteriors.items():
         assert q.shape == (1, 30 + 1 - 15) and np.isfinite(q).all()
+
+
+def test_dc_list_sweep_in_one_launch(pkg):
+    """RSF.inference_batched: every true Dc of dc_list is an observation group of independent chains."""
+    np.random.seed(4)
+    problem = pkg.RSF(number_slip_values=3, lowest_slip_value=500.0, largest_slip_value=2500.0, qstart=1000.0,
+                      qpriors=["Uniform", 0.0, 10000.0])
+    problem.model = pkg.RateStateModel(number_time_steps=500)
+    problem.data = problem.generate_time_series()
+    pools = problem.inference_batched(nsamples=120, chains_per_dc=256, seed=1)
+    assert sorted(pools) == [500.0, 1500.0, 2500.0]
+    for dc, pool in pools.items():
+        assert pool.samples.shape == (120 + 1 - 60, 256, 1)
+        x = pool.pooled()[0]
+        assert abs(x.mean() - dc) < 0.25 * dc, (dc, x.mean())
+        assert 0.2 < pool.accept_rate < 0.98

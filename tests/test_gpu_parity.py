@@ -188,6 +188,22 @@ def test_out_of_bounds_proposals_skip_the_solve(gpu_engine, cpu_engine, oracle_m
     assert (tg[0] > 980.0).all() and (tg[0] < 1020.0).all()
 
 
+def test_observation_groups(gpu_engine, cpu_engine, oracle_mod):
+    """One observation series per chain group: GPU vs oracle, and the group blocks are used."""
+    m = _models(oracle_mod, 500)
+    for e in (gpu_engine, cpu_engine):
+        e.set_model(m, 1)
+    G, per = 3, 256
+    data = np.stack([synthetic_data(cpu_engine, dc_true=dc, seed=20 + g) for g, dc in enumerate((300.0, 1000.0, 4000.0))])
+    q0 = np.full((G * per, 1), 900.0)
+    tg, tc = _run_pair(gpu_engine, cpu_engine, 25, G * per, q0, data, [0.0], [1e4], seed=8, prior_len=3)
+    _assert_chains_match(tg, tc)
+    means = [tg[0][10:, g * per:(g + 1) * per, 0].mean() for g in range(G)]
+    assert means[0] < means[1] < means[2]  # each group is pulled towards its own true Dc
+    with pytest.raises(Exception):
+        gpu_engine.mcmc_init(q0[:300], data, [0.0], [1e4])  # 100 chains per group: not a multiple of the workgroup
+
+
 def test_three_parameter_chains(gpu_engine, cpu_engine, oracle_mod):
     """Extension (BASELINE config 5): joint (Dc, a, b).  The reference-style initial covariance (X^T X)^-1 is
     nearly singular here (a and b are almost degenerate), so the chains start from an explicit proposal

@@ -174,3 +174,28 @@ def test_mcmc_statistical_sanity(cpu_engine, oracle_mod):
     assert 0.4 < ta.mean() < 0.95
     st = cpu_engine.stats()
     assert st["evaluated"] == 64 * 120 and st["nonfinite"] == 0 and st["iters_done"] == 120
+
+
+def test_observation_groups_equal_separate_runs(pkg, oracle_lib, oracle_mod):
+    """n_groups > 1 (one observation series per chain group, the dc_list sweep in one launch) is exactly the
+    same as one run per group with the matching chain_offset."""
+    from conftest import synthetic_data
+
+    m = oracle_mod.ModelSpec(500)
+    G, per = 3, 8
+    with pkg.Engine(lib=oracle_lib) as e:
+        e.set_model(m, 1)
+        data = np.stack([synthetic_data(e, dc_true=dc, seed=10 + g) for g, dc in enumerate((300.0, 1000.0, 4000.0))])
+        q0 = np.full((G * per, 1), 900.0)
+        e.mcmc_init(q0, data, [0.0], [1e4], seed=6, prior_len=3)
+        state_all = e.get_state()
+        tq, ts, ta = e.mcmc_run(15)
+        for g in range(G):
+            e.mcmc_init(q0[:per], data[g], [0.0], [1e4], seed=6, chain_offset=g * per, prior_len=3)
+            for k, x in enumerate(e.get_state()):
+                np.testing.assert_array_equal(x, state_all[k][g * per:(g + 1) * per])
+            one = e.mcmc_run(15)
+            for k, full in enumerate((tq, ts, ta)):
+                np.testing.assert_array_equal(one[k], full[:, g * per:(g + 1) * per])
+        with pytest.raises(ValueError):
+            e.mcmc_init(q0[:10], data, [0.0], [1e4])  # 10 chains do not split over 3 groups
