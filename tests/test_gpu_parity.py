@@ -289,23 +289,30 @@ def test_replay_of_reference_variates(gpu_engine, golden, oracle_mod):
         np.testing.assert_allclose(ts[nb - 1:, 0], g["std2_kept"], rtol=1e-5)
 
 
-def test_device_memory_path_and_full_size_properties(pkg, oracle_mod):
-    """BASELINE config 1 size (65 536 chains, nsteps 500) with device-resident buffers: determinism, and
-    shard invariance — splitting the chains into two ctxs by global id gives the identical pool."""
+@pytest.mark.parametrize("C,n,d,iters", [(65536, 500, 1, 5), (262144, 2000, 1, 2), (131072, 4000, 3, 1)])
+def test_device_memory_path_and_full_size_properties(pkg, oracle_mod, C, n, d, iters):
+    """BASELINE sizes (configs[1], configs[2], one GPU's share of configs[4]) with device-resident buffers,
+    checked through size-independent properties: determinism, and shard invariance — splitting the chains
+    into two ctxs by global chain id gives the identical pool (what makes the multi-GPU pool independent of
+    the GPU count)."""
     import torch
 
-    m = _models(oracle_mod, 500)
-    C = 65536
+    m = _models(oracle_mod, n)
     with pkg.Engine(mem="host") as e:
         e.set_model(m, 1)
         data = synthetic_data(e)
-    q0 = torch.full((C, 1), 1000.0, dtype=torch.float64, device="cuda")
+    start = [1000.0, 0.011, 0.014][:d]
+    q0 = torch.tensor(start, dtype=torch.float64, device="cuda").repeat(C, 1)
+    lo, hi = [0.0, 0.005, 0.005][:d], [1e4, 0.02, 0.03][:d]
+    V0 = torch.diag(torch.tensor([20.0 ** 2, 1e-4 ** 2, 1e-4 ** 2][:d], dtype=torch.float64, device="cuda"))
 
     def run(off, cnt):
         with pkg.Engine(mem="device") as e:
             e.set_model(m, 1)
-            e.mcmc_init(q0[off:off + cnt], data, [0.0], [1e4], seed=2025, chain_offset=off, prior_len=3)
-            tq, ts, ta = e.mcmc_run(5)
+            e.mcmc_init(q0[off:off + cnt], data, lo, hi, seed=2025, chain_offset=off, prior_len=3 if d == 1 else 0)
+            if d == 3:
+                e.set_state(V=V0.repeat(cnt, 1, 1))
+            tq, ts, ta = e.mcmc_run(iters)
             e.sync()
             return tq.cpu().numpy(), ts.cpu().numpy(), ta.cpu().numpy(), e.stats()
 
@@ -316,7 +323,8 @@ def test_device_memory_path_and_full_size_properties(pkg, oracle_mod):
     lo_half, hi_half = run(0, C // 2), run(C // 2, C // 2)
     for k in range(3):
         np.testing.assert_array_equal(np.concatenate([lo_half[k], hi_half[k]], axis=1), full[k])
-    assert full[3]["evaluated"] == 5 * C
-    acc_rate = full[3]["accepted"] / (5 * C)
+    assert full[3]["evaluated"] == iters * C and full[3]["nonfinite"] == 0
+    acc_rate = full[3]["accepted"] / (iters * C)
     assert 0.3 < acc_rate < 0.95
     assert np.isfinite(full[0]).all() and (full[1] > 0).all()
+    assert full[0].shape == (iters, C, d)
