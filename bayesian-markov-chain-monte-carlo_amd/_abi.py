@@ -96,6 +96,8 @@ PROTOTYPES = {
     "rsf_mcmc_run": (c_int, [c_void_p, c_int64, _P, _P, _P]),
     "rsf_mcmc_replay": (c_int, [c_void_p, c_int64, _P, _P, _P, _P, _P, _P]),
     "rsf_mcmc_stats": (c_int, [c_void_p, POINTER(c_int64), POINTER(c_int64), POINTER(c_int64), POINTER(c_int64)]),
+    "rsf_pool_summary": (c_int, [c_void_p, c_int64, _P, c_int64, POINTER(c_double)]),
+    "rsf_pool_kde": (c_int, [c_void_p, c_int64, _P, c_int64, c_int32, _P, c_double, _P]),
     "rsf_philox4x32_10": (c_int, [POINTER(c_uint32), POINTER(c_uint32), POINTER(c_uint32)]),
     "rsf_mcmc_draws": (c_int, [c_uint64, c_int64, c_int64, c_int32, c_double, POINTER(c_double), POINTER(c_double), POINTER(c_double)]),
 }

@@ -18,6 +18,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <cstring>
 #include <vector>
 
@@ -371,6 +372,76 @@ __global__ void __launch_bounds__(kMaxBlock) mcmc_kernel(Consts K, McmcArgs A) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// posterior post-processing on pooled samples (RSF.plot_dist, RSF.py:717-746)
+// ---------------------------------------------------------------------------------------------
+constexpr int kPoolBlocks = 1024;  // 4 workgroups per CU; partials are combined deterministically (no atomics)
+
+struct PoolPartial {
+  double cnt, sum, sumsq, mn, mx;  // sums are taken about a common shift for stability
+};
+
+__global__ void __launch_bounds__(kMaxBlock)
+pool_moments_kernel(int64_t n, const double *__restrict__ x, int64_t stride, double shift, PoolPartial *__restrict__ part) {
+  __shared__ PoolPartial sh[kMaxBlock / 64];
+  double cnt = 0.0, sum = 0.0, sumsq = 0.0, mn = INFINITY, mx = -INFINITY;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const double v = x[i * stride], dlt = v - shift;
+    cnt += 1.0; sum += dlt; sumsq = __builtin_fma(dlt, dlt, sumsq);
+    mn = fmin(mn, v); mx = fmax(mx, v);
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    cnt += __shfl_down(cnt, off, 64); sum += __shfl_down(sum, off, 64); sumsq += __shfl_down(sumsq, off, 64);
+    mn = fmin(mn, __shfl_down(mn, off, 64)); mx = fmax(mx, __shfl_down(mx, off, 64));
+  }
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = {cnt, sum, sumsq, mn, mx};
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    PoolPartial p = sh[0];
+    for (unsigned w = 1; w < blockDim.x / 64; ++w) {
+      p.cnt += sh[w].cnt; p.sum += sh[w].sum; p.sumsq += sh[w].sumsq; p.mn = fmin(p.mn, sh[w].mn); p.mx = fmax(p.mx, sh[w].mx);
+    }
+    part[blockIdx.x] = p;
+  }
+}
+
+// Each workgroup owns a contiguous slice of the samples, streamed through LDS in tiles; every thread
+// accumulates the kernel sum of its grid points over the slice (LDS broadcast reads).  partial[block][m].
+constexpr int kKdeTile = 1024;
+
+__global__ void __launch_bounds__(kMaxBlock)
+pool_kde_kernel(int64_t n, const double *__restrict__ x, int64_t stride, int m, const double *__restrict__ grid, double inv2c,
+                double *__restrict__ partial) {
+  __shared__ double tile[kKdeTile];
+  const int64_t per = (n + gridDim.x - 1) / gridDim.x, lo = (int64_t)blockIdx.x * per, hi = min(n, lo + per);
+  for (int j0 = 0; j0 < m; j0 += blockDim.x) {
+    const int j = j0 + threadIdx.x;
+    const double g = j < m ? grid[j] : 0.0;
+    double acc = 0.0;
+    for (int64_t t0 = lo; t0 < hi; t0 += kKdeTile) {
+      const int tn = (int)min((int64_t)kKdeTile, hi - t0);
+      __syncthreads();
+      for (int t = threadIdx.x; t < tn; t += blockDim.x) tile[t] = x[(t0 + t) * stride];
+      __syncthreads();
+      for (int t = 0; t < tn; ++t) {
+        const double dlt = g - tile[t];
+        acc += rsf::fm::exp(-dlt * dlt * inv2c);
+      }
+    }
+    if (j < m) partial[(int64_t)blockIdx.x * m + j] = acc;
+  }
+}
+
+__global__ void __launch_bounds__(kMaxBlock)
+pool_kde_reduce_kernel(int nblocks, int m, const double *__restrict__ partial, double norm, double *__restrict__ density) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= m) return;
+  double acc = 0.0;
+  for (int b = 0; b < nblocks; ++b) acc += partial[(int64_t)b * m + j];  // fixed order: reproducible
+  density[j] = acc * norm;
+}
+
 // out[0..3] = philox words (as doubles are not used here): layout documented at the call sites
 __global__ void probe_philox_kernel(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
                                     uint32_t *out) {
@@ -437,6 +508,7 @@ struct rsf_ctx {
   int64_t iters_done = 0;
   // staging for RSF_MEM_HOST callers
   DevBuf stage[8];
+  DevBuf pool;  // workspace of the posterior post-processing kernels
 };
 
 namespace {
@@ -620,6 +692,7 @@ int rsf_destroy(rsf_ctx *c) {
     free_chains(c);
     release(c->vl);
     for (auto &s : c->stage) release(s);
+    release(c->pool);
   }
   delete c;
   return RSF_OK;
@@ -847,6 +920,68 @@ int rsf_mcmc_stats(rsf_ctx *c, int64_t *n_acc, int64_t *n_eval, int64_t *n_nonfi
   if (n_nonfinite) *n_nonfinite = (int64_t)s[2];
   if (n_done) *n_done = c->iters_done;
   return RSF_OK;
+}
+
+namespace {
+
+// moments of x[i*stride] with x already a device pointer; result on the host
+int pool_moments(rsf_ctx *c, int64_t n, const double *dx, int64_t stride, double out[5]) {
+  int rc = ensure(c->pool, sizeof(PoolPartial) * kPoolBlocks);
+  if (rc) return rc;
+  double shift = 0.0;
+  HIP_TRY(hipMemcpyAsync(&shift, dx, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  const int blocks = (int)std::min<int64_t>(kPoolBlocks, (n + kMaxBlock - 1) / kMaxBlock);
+  hipLaunchKernelGGL(pool_moments_kernel, dim3(blocks), dim3(kMaxBlock), 0, c->stream, n, dx, stride, shift, (PoolPartial *)c->pool.p);
+  std::vector<PoolPartial> h(blocks);
+  HIP_TRY(hipMemcpyAsync(h.data(), c->pool.p, sizeof(PoolPartial) * blocks, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  double cnt = 0, sum = 0, sumsq = 0, mn = INFINITY, mx = -INFINITY;
+  for (const auto &p : h) { cnt += p.cnt; sum += p.sum; sumsq += p.sumsq; mn = std::fmin(mn, p.mn); mx = std::fmax(mx, p.mx); }
+  const double mean_s = sum / cnt;
+  out[0] = cnt; out[1] = shift + mean_s;
+  out[2] = cnt > 1 ? (sumsq - cnt * mean_s * mean_s) / (cnt - 1) : 0.0;
+  out[3] = mn; out[4] = mx;
+  return RSF_OK;
+}
+
+}  // namespace
+
+int rsf_pool_summary(rsf_ctx *c, int64_t n, const double *x, int64_t stride, double *out) {
+  if (!c || !x || !out || n < 1 || stride < 1) return fail(RSF_ERR_INVALID, "rsf_pool_summary: bad argument");
+  DeviceGuard guard(c->device);
+  if (!guard.ok) return fail(RSF_ERR_DEVICE, "rsf_pool_summary: cannot select device %d", c->device);
+  const void *dx;
+  int rc = stage_in(c, 0, x, (size_t)((n - 1) * stride + 1) * sizeof(double), &dx);
+  if (rc) return rc;
+  return pool_moments(c, n, (const double *)dx, stride, out);
+}
+
+int rsf_pool_kde(rsf_ctx *c, int64_t n, const double *x, int64_t stride, int32_t m, const double *grid, double bw_factor,
+                 double *density) {
+  if (!c || !x || !grid || !density || n < 2 || m < 1 || stride < 1) return fail(RSF_ERR_INVALID, "rsf_pool_kde: bad argument");
+  DeviceGuard guard(c->device);
+  if (!guard.ok) return fail(RSF_ERR_DEVICE, "rsf_pool_kde: cannot select device %d", c->device);
+  const void *dx, *dg;
+  void *dd;
+  int rc;
+  if ((rc = stage_in(c, 0, x, (size_t)((n - 1) * stride + 1) * sizeof(double), &dx))) return rc;
+  if ((rc = stage_in(c, 1, grid, (size_t)m * sizeof(double), &dg))) return rc;
+  if ((rc = stage_out(c, 2, density, (size_t)m * sizeof(double), &dd))) return rc;
+  double s[5];
+  if ((rc = pool_moments(c, n, (const double *)dx, stride, s))) return rc;
+  const double factor = bw_factor > 0.0 ? bw_factor : std::pow((double)n, -1.0 / 5.0);  // scipy scotts_factor, d = 1
+  const double cov = s[2] * factor * factor;
+  if (!(cov > 0.0)) return fail(RSF_ERR_INVALID, "rsf_pool_kde: the samples have zero variance (singular KDE)");
+  const int blocks = (int)std::min<int64_t>(kPoolBlocks, (n + kKdeTile - 1) / kKdeTile);
+  DevBuf &ws = c->stage[7];
+  if ((rc = ensure(ws, (size_t)blocks * (size_t)m * sizeof(double)))) return rc;
+  hipLaunchKernelGGL(pool_kde_kernel, dim3(blocks), dim3(kMaxBlock), 0, c->stream, n, (const double *)dx, stride, (int)m,
+                     (const double *)dg, 0.5 / cov, (double *)ws.p);
+  hipLaunchKernelGGL(pool_kde_reduce_kernel, dim3((m + kMaxBlock - 1) / kMaxBlock), dim3(kMaxBlock), 0, c->stream, blocks, (int)m,
+                     (const double *)ws.p, 1.0 / ((double)n * std::sqrt(2.0 * 3.14159265358979323846 * cov)), (double *)dd);
+  if ((rc = copy_back(c, 2, density, (size_t)m * sizeof(double)))) return rc;
+  return finish(c);
 }
 
 int rsf_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {

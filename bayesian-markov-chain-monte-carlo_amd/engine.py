@@ -191,6 +191,31 @@ class Engine:
         _abi.check(self.lib, self.lib.rsf_mcmc_stats(self._ctx, *[ctypes.byref(x) for x in v]))
         return dict(zip(("accepted", "evaluated", "nonfinite", "iters_done"), (x.value for x in v)))
 
+    # -- posterior post-processing (RSF.plot_dist, RSF.py:717-746) -------------------------
+    def _column(self, samples, param):
+        """samples: (n,) or trace block (..., d) in this engine's memory space → (array, n, stride)."""
+        x = self._in(samples)
+        d = int(x.shape[-1]) if x.ndim > 1 else 1
+        n = int(np.prod(x.shape)) // d
+        return x, n, d, int(param)
+
+    def pool_summary(self, samples, param=0):
+        """→ dict(n, mean, var (ddof=1), min, max) of parameter `param` over all pooled draws."""
+        x, n, d, p = self._column(samples, param)
+        out = (ctypes.c_double * 5)()
+        _abi.check(self.lib, self.lib.rsf_pool_summary(self._ctx, n, self._ptr(x) + 8 * p, d, out))
+        return dict(zip(("n", "mean", "var", "min", "max"), list(out)))
+
+    def pool_kde(self, samples, grid, param=0, bw_factor=0.0):
+        """scipy.stats.gaussian_kde(samples).pdf(grid) (Scott bandwidth unless bw_factor > 0) → density[m]."""
+        x, n, d, p = self._column(samples, param)
+        grid = self._in(grid)
+        m = int(grid.shape[0])
+        dens = self._empty((m,))
+        _abi.check(self.lib, self.lib.rsf_pool_kde(self._ctx, n, self._ptr(x) + 8 * p, d, m, self._ptr(grid), float(bw_factor),
+                                                   self._ptr(dens)))
+        return dens
+
     # -- RNG helpers (tests) --------------------------------------------------------------
     def philox(self, ctr, key):
         c, k, o = (ctypes.c_uint32 * 4)(*ctr), (ctypes.c_uint32 * 2)(*key), (ctypes.c_uint32 * 4)()

@@ -12,6 +12,7 @@
  *   MCMC.update_standard_deviation      MCMC.py:129-160
  *   MCMC.update_covariance_matrix       MCMC.py:162-204
  *   MCMC.sample (hot loop)              MCMC.py:391-544
+ *   RSF.plot_dist (KDE of the samples)  RSF.py:717-746
  *
  * Two shared libraries implement this same header:
  *   - librsf_hip.so     (the product: hand-written gfx950 HIP kernels)
@@ -181,6 +182,19 @@ int rsf_mcmc_replay(rsf_ctx *ctx, int64_t n_iters, const double *z, const double
  * done per chain.  Any pointer may be NULL. */
 int rsf_mcmc_stats(rsf_ctx *ctx, int64_t *n_accepted, int64_t *n_evaluated, int64_t *n_nonfinite,
                    int64_t *n_iters_done);
+
+/* ---- posterior post-processing on pooled samples (RSF.plot_dist, RSF.py:717-746) -------------- */
+
+/* Moments of n samples x[i*stride] (stride in doubles selects one parameter of a [n][d] trace block):
+ *   out[0] = n, out[1] = mean, out[2] = variance (ddof = 1, as np.cov / gaussian_kde), out[3] = min, out[4] = max.
+ * `out` is a HOST array of 5 doubles in every mem_space; x follows the ctx mem_space. */
+int rsf_pool_summary(rsf_ctx *ctx, int64_t n, const double *x, int64_t stride, double *out);
+
+/* Gaussian kernel density estimate on m grid points, scipy.stats.gaussian_kde semantics (RSF.py:733-736):
+ *   density[j] = 1/(n sqrt(2 pi c)) * sum_i exp(-(grid[j]-x_i)^2 / (2 c)),   c = var(x, ddof=1) * factor^2,
+ * factor = n^(-1/5) (Scott's rule) when bw_factor <= 0, else bw_factor.  grid[m], density[m] follow mem_space. */
+int rsf_pool_kde(rsf_ctx *ctx, int64_t n, const double *x, int64_t stride, int32_t m, const double *grid,
+                 double bw_factor, double *density);
 
 /* The Philox4x32-10 block function itself (known-answer tests; Random123 vectors). */
 int rsf_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);

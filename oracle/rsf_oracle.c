@@ -540,6 +540,45 @@ int rsf_mcmc_stats(rsf_ctx *c, int64_t *n_acc, int64_t *n_eval, int64_t *n_nonfi
   return RSF_OK;
 }
 
+/* ------------------------------------------------------------------------------------ */
+/* posterior post-processing (RSF.plot_dist, RSF.py:717-746)                              */
+/* ------------------------------------------------------------------------------------ */
+int rsf_pool_summary(rsf_ctx *c, int64_t n, const double *x, int64_t stride, double *out) {
+  if (!c || !x || !out || n < 1 || stride < 1) return fail(RSF_ERR_INVALID, "rsf_pool_summary: bad argument");
+  double mean = 0.0, mn = x[0], mx = x[0], ss = 0.0;
+  for (int64_t i = 0; i < n; ++i) {
+    double v = x[i * stride];
+    mean += v;
+    if (v < mn) mn = v;
+    if (v > mx) mx = v;
+  }
+  mean /= (double)n;
+  for (int64_t i = 0; i < n; ++i) { double dlt = x[i * stride] - mean; ss += dlt * dlt; }  /* two-pass, like np.cov */
+  out[0] = (double)n; out[1] = mean; out[2] = n > 1 ? ss / (double)(n - 1) : 0.0; out[3] = mn; out[4] = mx;
+  return RSF_OK;
+}
+
+int rsf_pool_kde(rsf_ctx *c, int64_t n, const double *x, int64_t stride, int32_t m, const double *grid, double bw_factor,
+                 double *density) {
+  if (!c || !x || !grid || !density || n < 2 || m < 1 || stride < 1) return fail(RSF_ERR_INVALID, "rsf_pool_kde: bad argument");
+  double s[5];
+  int rc = rsf_pool_summary(c, n, x, stride, s);
+  if (rc) return rc;
+  double factor = bw_factor > 0.0 ? bw_factor : pow((double)n, -1.0 / 5.0);  /* scipy scotts_factor, d = 1 */
+  double cov = s[2] * factor * factor;
+  if (!(cov > 0.0)) return fail(RSF_ERR_INVALID, "rsf_pool_kde: the samples have zero variance (singular KDE)");
+  double norm = 1.0 / ((double)n * sqrt(2.0 * 3.14159265358979323846 * cov)), inv2c = 0.5 / cov;
+  int nt = nthreads(c);
+  (void)nt;
+#pragma omp parallel for schedule(static) num_threads(nt)
+  for (int32_t j = 0; j < m; ++j) {
+    double acc = 0.0;
+    for (int64_t i = 0; i < n; ++i) { double dlt = grid[j] - x[i * stride]; acc += exp(-dlt * dlt * inv2c); }
+    density[j] = acc * norm;
+  }
+  return RSF_OK;
+}
+
 int rsf_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
   if (!ctr || !key || !out) return fail(RSF_ERR_INVALID, "rsf_philox4x32_10: NULL argument");
   philox_block(ctr, key, out);

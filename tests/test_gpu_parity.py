@@ -188,6 +188,32 @@ def test_out_of_bounds_proposals_skip_the_solve(gpu_engine, cpu_engine, oracle_m
     assert (tg[0] > 980.0).all() and (tg[0] < 1020.0).all()
 
 
+def test_pool_summary_and_kde(pkg, cpu_engine):
+    """Device reductions over pooled samples vs the oracle and scipy.stats.gaussian_kde (host and device buffers)."""
+    import torch
+    from scipy.stats import gaussian_kde
+
+    rng = np.random.default_rng(4)
+    n = 200_003
+    trace = np.stack([rng.normal(1000.0, 40.0, n), rng.normal(0.011, 1e-3, n), rng.gamma(3.0, 2.0, n)], axis=1).reshape(-1, 1, 3)
+    grid = np.linspace(800.0, 1200.0, 1000)
+    with pkg.Engine(mem="host") as eh, pkg.Engine(mem="device") as ed:
+        for p in range(3):
+            x = trace[..., p].ravel()
+            ref = cpu_engine.pool_summary(trace, param=p)
+            for e, arr in ((eh, trace), (ed, torch.as_tensor(trace).cuda())):
+                s = e.pool_summary(arr, param=p)
+                np.testing.assert_allclose([s[k] for k in ("n", "mean", "var", "min", "max")],
+                                           [ref[k] for k in ("n", "mean", "var", "min", "max")], rtol=1e-11)
+        dens_h = eh.pool_kde(trace, grid, param=0)
+        dens_d = ed.pool_kde(torch.as_tensor(trace).cuda(), torch.as_tensor(grid).cuda(), param=0).cpu().numpy()
+        np.testing.assert_array_equal(dens_h, dens_d)  # fixed-order reduction: reproducible
+        sub = trace[:5000]
+        np.testing.assert_allclose(eh.pool_kde(sub, grid, param=0), gaussian_kde(sub[..., 0].ravel()).pdf(grid), rtol=1e-9, atol=1e-300)
+        np.testing.assert_allclose(eh.pool_kde(sub, grid, param=0), cpu_engine.pool_kde(sub, grid, param=0), rtol=1e-10, atol=1e-300)
+        assert abs(np.trapezoid(dens_h, grid) - 1.0) < 1e-3
+
+
 def test_observation_groups(gpu_engine, cpu_engine, oracle_mod):
     """One observation series per chain group: GPU vs oracle, and the group blocks are used."""
     m = _models(oracle_mod, 500)

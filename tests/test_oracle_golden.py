@@ -199,3 +199,20 @@ def test_observation_groups_equal_separate_runs(pkg, oracle_lib, oracle_mod):
                 np.testing.assert_array_equal(one[k], full[:, g * per:(g + 1) * per])
         with pytest.raises(ValueError):
             e.mcmc_init(q0[:10], data, [0.0], [1e4])  # 10 chains do not split over 3 groups
+
+
+def test_pool_summary_and_kde_match_numpy_and_scipy(cpu_engine):
+    """Posterior post-processing (RSF.plot_dist, RSF.py:717-746): moments and the Scott-bandwidth Gaussian KDE."""
+    from scipy.stats import gaussian_kde
+
+    rng = np.random.default_rng(3)
+    trace = np.stack([rng.normal(1000.0, 40.0, 3000), rng.normal(0.011, 1e-3, 3000), rng.gamma(3.0, 2.0, 3000)], axis=1)
+    for p in range(3):
+        x = trace[:, p]
+        s = cpu_engine.pool_summary(trace, param=p)
+        np.testing.assert_allclose([s["n"], s["mean"], s["var"], s["min"], s["max"]],
+                                   [x.size, x.mean(), x.var(ddof=1), x.min(), x.max()], rtol=1e-12)
+        grid = np.linspace(x.min() - x.std(), x.max() + x.std(), 200)
+        np.testing.assert_allclose(cpu_engine.pool_kde(trace, grid, param=p), gaussian_kde(x).pdf(grid), rtol=1e-10, atol=1e-300)
+    with pytest.raises(Exception):
+        cpu_engine.pool_kde(np.full(10, 3.0), np.linspace(0, 1, 5))  # zero variance: singular, like scipy
