@@ -1,7 +1,9 @@
 // rsf_device.h — device-side building blocks of the gfx950 kernels (included by rsf_hip.hip only).
 //
 //   Philox4x32-10 counter RNG + Box-Muller normals + Marsaglia-Tsang gamma   (K3)
-//   rate-and-state friction RHS and one classical RK4 step per lane           (K1 core)
+//   rate-and-state friction RHS and the classical RK4 step, per lane          (K1 core)
+//     hot path: steps in pairs, transcendentals carried incrementally (rk4_fast / integrate_pairs)
+//     cold path: full log/exp evaluation (rk4_cold), taken when an increment leaves the series' guard region
 //   cooperative LDS staging of the chain-independent tables (loading V_l(t), observation)
 //
 // One lane integrates one chain; a wave64 is 64 independent chains.  The time recurrence is
@@ -80,6 +82,7 @@ __device__ __forceinline__ Lane make_lane(double dc, double a, double b, const C
 // Same quantities as the reference, regrouped so that every reciprocal is hoisted into Lane and
 // the slip rate appears only as w = v/V_ref = exp((mu-mu_ref)/a - (b/a) log(V_ref*theta/Dc)).
 // ---------------------------------------------------------------------------------------------
+
 // Integration state of one lane: ms = mu/k', x = theta/Dc, V, and the transcendental parts of the RHS at
 // that point:  w = v/V_ref = exp(mu/a - mu_ref/a - (b/a) log(V_ref x)),   rx = 1/x.
 struct State {
@@ -115,19 +118,19 @@ __device__ __forceinline__ void eval_full(double ms, double x, const Lane &L, co
 
 // (w', 1/x') at (ms + dms, x1 = x + dx) from (w, rx) at (ms, x).  With rho = dx/x (= dtheta/theta) and
 // dlt = dmu/a - (b/a) log1p(rho), dmu/a = kia*dms:   w' = w exp(dlt),   1/x' = (1/x)/(1 + rho),
-// by short series — the same function of (mu', th') to rounding inside the guard region:
+// by short series — the same function of (ms', x') to rounding inside the guard region:
 //   |dlt| < 2^-6 : expm1 to dlt^7/5040                      (next term < 9e-20)
-//   NARROW |rho| < 2^-9 : log1p to rho^6/6, 1/th' by a 2nd-order start + 1 Newton step (rho^6 < 2^-54)
-//   WIDE   |rho| < 2^-7 : log1p to rho^7/7, 1/th' by a 1st-order start + 2 Newton steps (rho^8 < 2^-56)
-// `grho` / `gdlt` track the largest |rho| / |dlt| seen since they were last reset.
+//   NARROW |rho| < 2^-9 : log1p to rho^6/6, 1/x' by a 2nd-order start + 1 Newton step (rho^6 < 2^-54)
+//   WIDE   |rho| < 2^-7 : log1p to rho^7/7, 1/x' by a 1st-order start + 2 Newton steps (rho^8 < 2^-56)
+// Guard tracks the largest |rho| / |dlt| seen since it was last reset.
 struct Guard {
   double rho, dlt;
 };
 
 template <bool WIDE>
-__device__ __forceinline__ void eval_incr(double dms, double dx, double th1, const Lane &L, double w0, double rth0,
-                                          double &w, double &rth, Guard &g) {
-  const double rho = dx * rth0;
+__device__ __forceinline__ void eval_incr(double dms, double dx, double x1, const Lane &L, double w0, double rx0,
+                                          double &w, double &rx, Guard &g) {
+  const double rho = dx * rx0;
   g.rho = __builtin_fmax(g.rho, __builtin_fabs(rho));
   double p;
   if (WIDE) {
@@ -150,12 +153,12 @@ __device__ __forceinline__ void eval_incr(double dms, double dx, double th1, con
   e = __builtin_fma(e, dlt, 1.0);
   w = __builtin_fma(w0, e * dlt, w0);
   if (WIDE) {
-    rth = __builtin_fma(-rho, rth0, rth0);
-    rth = __builtin_fma(rth, __builtin_fma(-th1, rth, 1.0), rth);
-    rth = __builtin_fma(rth, __builtin_fma(-th1, rth, 1.0), rth);
+    rx = __builtin_fma(-rho, rx0, rx0);
+    rx = __builtin_fma(rx, __builtin_fma(-x1, rx, 1.0), rx);
+    rx = __builtin_fma(rx, __builtin_fma(-x1, rx, 1.0), rx);
   } else {
-    rth = __builtin_fma(rth0, __builtin_fma(rho, rho, -rho), rth0);
-    rth = __builtin_fma(rth, __builtin_fma(-th1, rth, 1.0), rth);
+    rx = __builtin_fma(rx0, __builtin_fma(rho, rho, -rho), rx0);
+    rx = __builtin_fma(rx, __builtin_fma(-x1, rx, 1.0), rx);
   }
 }
 

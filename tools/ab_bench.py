@@ -24,6 +24,8 @@ def main():
     ap.add_argument("--nsteps", type=int, default=500)
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--rounds", type=int, default=7)
+    ap.add_argument("--params", type=int, default=1, choices=[1, 3], help="1: Dc;  3: (Dc, a, b)")
+    ap.add_argument("--precision", default="float64", choices=["float64", "float32"])
     ap.add_argument("variants", nargs="*")
     args = ap.parse_args()
 
@@ -37,14 +39,18 @@ def main():
         name, path = v.split("=", 1)
         libs[name] = pkg._abi.bind(ctypes.CDLL(os.path.abspath(path)))
     model, data = synthetic_problem(args.nsteps)
-    C, ips = args.chains, args.iters
-    engines, traces = {}, (torch.empty((ips, C, 1), dtype=torch.float64, device="cuda"),
+    model.precision = args.precision
+    C, ips, d = args.chains, args.iters, args.params
+    engines, traces = {}, (torch.empty((ips, C, d), dtype=torch.float64, device="cuda"),
                            torch.empty((ips, C), dtype=torch.float64, device="cuda"), None)
-    q0 = torch.full((C, 1), 1000.0, dtype=torch.float64, device="cuda")
+    q0 = torch.tensor([1000.0, 0.011, 0.014][:d], dtype=torch.float64, device="cuda").repeat(C, 1)
+    V0 = torch.diag(torch.tensor([20.0 ** 2, 1e-4 ** 2, 1e-4 ** 2][:d], dtype=torch.float64, device="cuda")).repeat(C, 1, 1)
     for name, lib in libs.items():
         e = pkg.Engine(lib=lib, mem="device")
         e.set_model(model, 1)
-        e.mcmc_init(q0, data, [0.0], [1.0e4], seed=2025, prior_len=3)
+        e.mcmc_init(q0, data, [0.0, 0.005, 0.005][:d], [1.0e4, 0.02, 0.03][:d], seed=2025, prior_len=3 if d == 1 else 0)
+        if d == 3:
+            e.set_state(V=V0)
         e.mcmc_run(ips, out=traces)  # warm-up
         engines[name] = e
     torch.cuda.synchronize()
@@ -58,7 +64,7 @@ def main():
             torch.cuda.synchronize()
             times[name].append(a.elapsed_time(b))
     work = C * ips * args.nsteps
-    print(f"chains={C} nsteps={args.nsteps} iters/launch={ips} rounds={args.rounds}")
+    print(f"chains={C} nsteps={args.nsteps} iters/launch={ips} rounds={args.rounds} params={d} {args.precision}")
     for name, t in times.items():
         med, mn = float(np.median(t)), float(np.min(t))
         print(f"  {name:16s} median {med:9.3f} ms  min {mn:9.3f} ms   {work / (med * 1e-3):.4e} steps*chains/s")
