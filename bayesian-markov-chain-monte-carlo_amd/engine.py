@@ -112,8 +112,17 @@ class Engine:
         self.nout = n.value
         return self.nout
 
+    def _need_model(self):
+        if self.nout is None:
+            raise _abi.RsfError(-3, "call set_model first")
+
+    def _need_chains(self):
+        if self.n_chains is None:
+            raise _abi.RsfError(-3, "call mcmc_init first")
+
     def forward(self, dc, a=None, b=None, data=None, want_ssq=False, want_acc=True):
         """→ (ssq[C] | None, acc[nout, C] | None) for C parameter sets."""
+        self._need_model()
         dc = self._in(np.atleast_1d(dc) if not hasattr(dc, "data_ptr") else dc)
         C = int(dc.shape[0])
         a, b, data = self._in(a), self._in(b), self._in(data)
@@ -130,6 +139,7 @@ class Engine:
     # -- sampler --------------------------------------------------------------------------
     def mcmc_init(self, q0, data, lo, hi, seed=0, chain_offset=0, n0=0.01, prior_len=0, adapt_mode="none",
                   adapt_interval=10, fd_rel_step=1e-6):
+        self._need_model()
         q0 = self._in(q0)
         if q0.ndim == 1:
             q0 = q0.reshape(-1, 1)
@@ -153,6 +163,7 @@ class Engine:
         self.n_chains, self.n_params = C, d
 
     def get_state(self):
+        self._need_chains()
         C, d = self.n_chains, self.n_params
         q, ssq, std2, V = self._empty((C, d)), self._empty((C,)), self._empty((C,)), self._empty((C, d, d))
         _abi.check(self.lib, self.lib.rsf_mcmc_get_state(self._ctx, self._ptr(q), self._ptr(ssq), self._ptr(std2), self._ptr(V)))
@@ -163,6 +174,7 @@ class Engine:
         _abi.check(self.lib, self.lib.rsf_mcmc_set_state(self._ctx, self._ptr(q), self._ptr(ssq), self._ptr(std2), self._ptr(V)))
 
     def _traces(self, n_iters, want):
+        self._need_chains()
         C, d = self.n_chains, self.n_params
         if want is True:
             want = ("q", "std2", "accept")

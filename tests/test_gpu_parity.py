@@ -188,6 +188,65 @@ def test_out_of_bounds_proposals_skip_the_solve(gpu_engine, cpu_engine, oracle_m
     assert (tg[0] > 980.0).all() and (tg[0] < 1020.0).all()
 
 
+def test_edge_cases_and_call_order(pkg, cpu_engine, oracle_mod):
+    m = _models(oracle_mod, 500)
+    cpu_engine.set_model(m, 1)
+    data = synthetic_data(cpu_engine)
+    for block in (64, 128, 192, 256):  # every legal workgroup size gives the same numbers
+        with pkg.Engine(mem="host", block_threads=block) as e:
+            e.set_model(m, 1)
+            dc = np.linspace(200.0, 4000.0, 321)
+            s, a = e.forward(dc, data=data, want_ssq=True)
+            if block == 64:
+                ref = (s, a)
+            np.testing.assert_array_equal(s, ref[0])
+            np.testing.assert_array_equal(a, ref[1])
+    with pytest.raises(pkg._abi.RsfError):
+        pkg.Engine(mem="host", block_threads=96)
+    with pkg.Engine(mem="host") as e:
+        with pytest.raises(pkg._abi.RsfError):  # model not set
+            e.forward([1000.0])
+        e.set_model(m, 1)
+        ssq, acc = e.forward(np.empty(0))  # empty batch
+        assert acc.shape == (500, 0)
+        with pytest.raises(pkg._abi.RsfError):  # chains not initialised
+            e.mcmc_run(1)
+        # one chain, huge global chain id (64-bit Philox counter), zero iterations, then a few
+        e.mcmc_init([[1000.0]], data, [0.0], [1e4], seed=7, chain_offset=2 ** 33 + 7, prior_len=3)
+        cpu_engine.mcmc_init([[1000.0]], data, [0.0], [1e4], seed=7, chain_offset=2 ** 33 + 7, prior_len=3)
+        e.set_state(*cpu_engine.get_state())
+        assert e.mcmc_run(0)[0].shape == (0, 1, 1) and e.stats()["iters_done"] == 0
+        tg, tc = e.mcmc_run(12), cpu_engine.mcmc_run(12)
+        np.testing.assert_array_equal(tg[2], tc[2])
+        np.testing.assert_allclose(tg[0], tc[0], rtol=RTOL)
+        # a new model with another series length invalidates the chains (the observation no longer fits)
+        e.set_model(_models(oracle_mod, 400), 1)
+        with pytest.raises(pkg._abi.RsfError):
+            e.mcmc_run(1)
+
+
+def test_replay_three_parameters(gpu_engine, cpu_engine, oracle_mod):
+    """Caller-supplied variates with d = 3 (z has three columns, lower-Cholesky proposal)."""
+    m = _models(oracle_mod, 500)
+    for e in (gpu_engine, cpu_engine):
+        e.set_model(m, 1)
+    data = synthetic_data(cpu_engine)
+    C, n = 64, 15
+    rng = np.random.default_rng(12)
+    z, u, g = rng.standard_normal((n, C, 3)), rng.uniform(size=(n, C)), rng.gamma(250.005, size=(n, C))
+    q0 = np.tile([1000.0, 0.011, 0.014], (C, 1))
+    A = rng.standard_normal((3, 3)) * [[20.0], [1e-4], [1e-4]]
+    V0 = np.tile(A @ A.T + np.diag([1.0, 1e-10, 1e-10]), (C, 1, 1))  # a full (correlated) covariance
+    for e in (gpu_engine, cpu_engine):
+        e.mcmc_init(q0, data, [0.0, 0.005, 0.005], [1e4, 0.02, 0.03], seed=1)
+    q, ssq, std2, _ = cpu_engine.get_state()
+    for e in (gpu_engine, cpu_engine):
+        e.set_state(q, ssq, std2, V0)
+    tg, tc = gpu_engine.mcmc_replay(z, u, g), cpu_engine.mcmc_replay(z, u, g)
+    same = _assert_chains_match(tg, tc, min_same=0.95)
+    assert 0.05 < tg[2].mean() < 0.98 and same.any()
+
+
 def test_pool_summary_and_kde(pkg, cpu_engine):
     """Device reductions over pooled samples vs the oracle and scipy.stats.gaussian_kde (host and device buffers)."""
     import torch
