@@ -368,10 +368,10 @@ __device__ __forceinline__ void integrate_chunk(const double *lds, const Consts 
   }
 }
 
-// Full forward solve for one lane.  RESIDENT: the single chunk is already staged (no barriers,
-// so inactive lanes/waves may skip the call); otherwise all threads must call it.
-template <bool DAMP, bool WANT_SSQ, bool WANT_ACC, bool RESIDENT>
-__device__ __forceinline__ double solve(double *lds, const Consts &K, bool active, double dc, double a,
+// Full forward solve for one lane.  Every thread of the workgroup must call it (chunk staging has barriers);
+// `resident` (workgroup-uniform): the single chunk is already staged, nothing is re-staged.
+template <bool DAMP, bool WANT_SSQ, bool WANT_ACC>
+__device__ __forceinline__ double solve(double *lds, const Consts &K, bool resident, bool active, double dc, double a,
                                         double b, double *acc_out, int64_t stride) {
   const Lane L = make_lane(dc, a, b, K);
   State s = initial_state(dc, L, K);
@@ -381,14 +381,10 @@ __device__ __forceinline__ double solve(double *lds, const Consts &K, bool activ
     ssq = d0 * d0;
   }
   if (WANT_ACC && active) acc_out[0] = 0.0;
-  if (RESIDENT) {
-    if (active) integrate_chunk<DAMP, WANT_SSQ, WANT_ACC>(lds, K, L, 1, K.nout - 1, s, ssq, acc_out, stride);
-  } else {
-    for (int k0 = 1; k0 < K.nout; k0 += K.kc) {
-      const int kn = min(K.kc, K.nout - k0);
-      stage_chunk(lds, K, k0, kn);
-      if (active) integrate_chunk<DAMP, WANT_SSQ, WANT_ACC>(lds, K, L, k0, kn, s, ssq, acc_out, stride);
-    }
+  for (int k0 = 1; k0 < K.nout; k0 += K.kc) {
+    const int kn = min(K.kc, K.nout - k0);
+    if (!resident) stage_chunk(lds, K, k0, kn);
+    if (active) integrate_chunk<DAMP, WANT_SSQ, WANT_ACC>(lds, K, L, k0, kn, s, ssq, acc_out, stride);
   }
   return ssq;
 }

@@ -104,9 +104,9 @@ __device__ __forceinline__ void integrate_chunk32(const float *lds, const Consts
   }
 }
 
-template <bool DAMP, bool WANT_SSQ, bool WANT_ACC, bool RESIDENT>
-__device__ __forceinline__ double solve32(float *lds, const Consts &K, bool active, double dc, double a, double b,
-                                          double *acc_out, int64_t stride) {
+template <bool DAMP, bool WANT_SSQ, bool WANT_ACC>
+__device__ __forceinline__ double solve32(float *lds, const Consts &K, bool resident, bool active, double dc, double a,
+                                          double b, double *acc_out, int64_t stride) {
   const Lane32 L = make_lane32(dc, a, b, K);
   float ms = (float)(K.mu0 / ((1e-2 * 10) / dc)), x = (float)(1.0 / K.V_ref);
   double ssq = 0.0;
@@ -115,14 +115,10 @@ __device__ __forceinline__ double solve32(float *lds, const Consts &K, bool acti
     ssq = d0 * d0;
   }
   if (WANT_ACC && active) acc_out[0] = 0.0;
-  if (RESIDENT) {
-    if (active) integrate_chunk32<DAMP, WANT_SSQ, WANT_ACC>(lds, K, L, 1, K.nout - 1, ms, x, ssq, acc_out, stride);
-  } else {
-    for (int k0 = 1; k0 < K.nout; k0 += K.kc) {
-      const int kn = min(K.kc, K.nout - k0);
-      stage_chunk32(lds, K, k0, kn);
-      if (active) integrate_chunk32<DAMP, WANT_SSQ, WANT_ACC>(lds, K, L, k0, kn, ms, x, ssq, acc_out, stride);
-    }
+  for (int k0 = 1; k0 < K.nout; k0 += K.kc) {
+    const int kn = min(K.kc, K.nout - k0);
+    if (!resident) stage_chunk32(lds, K, k0, kn);
+    if (active) integrate_chunk32<DAMP, WANT_SSQ, WANT_ACC>(lds, K, L, k0, kn, ms, x, ssq, acc_out, stride);
   }
   return ssq;
 }

@@ -63,22 +63,15 @@ forward_kernel(Consts K, int64_t n, const double *__restrict__ dc, const double 
   const double ai = (active && a) ? a[i] : K.a_def;
   const double bi = (active && b) ? b[i] : K.b_def;
   double *acc_i = WANT_ACC ? acc_out + i : nullptr;
+  const bool resident = K.nchunks == 1;
   double ssq;
   if constexpr (F32) {
     float *lds32 = reinterpret_cast<float *>(lds);
-    if (K.nchunks == 1) {
-      rsf::f32::stage_chunk32(lds32, K, 1, K.nout - 1);
-      ssq = rsf::f32::solve32<DAMP, WANT_SSQ, WANT_ACC, true>(lds32, K, active, dci, ai, bi, acc_i, n);
-    } else {
-      ssq = rsf::f32::solve32<DAMP, WANT_SSQ, WANT_ACC, false>(lds32, K, active, dci, ai, bi, acc_i, n);
-    }
+    if (resident) rsf::f32::stage_chunk32(lds32, K, 1, K.nout - 1);
+    ssq = rsf::f32::solve32<DAMP, WANT_SSQ, WANT_ACC>(lds32, K, resident, active, dci, ai, bi, acc_i, n);
   } else {
-    if (K.nchunks == 1) {
-      rsf::stage_chunk(lds, K, 1, K.nout - 1);
-      ssq = rsf::solve<DAMP, WANT_SSQ, WANT_ACC, true>(lds, K, active, dci, ai, bi, acc_i, n);
-    } else {
-      ssq = rsf::solve<DAMP, WANT_SSQ, WANT_ACC, false>(lds, K, active, dci, ai, bi, acc_i, n);
-    }
+    if (resident) rsf::stage_chunk(lds, K, 1, K.nout - 1);
+    ssq = rsf::solve<DAMP, WANT_SSQ, WANT_ACC>(lds, K, resident, active, dci, ai, bi, acc_i, n);
   }
   if (WANT_SSQ && active) ssq_out[i] = ssq;
 }
@@ -171,7 +164,7 @@ __global__ void __launch_bounds__(kMaxBlock) ssq32_kernel(Consts K, int64_t C, c
   const bool active = i < C;
   const double dc = active ? q[i * D] : 1.0;
   const double a = (active && D == 3) ? q[i * D + 1] : K.a_def, b = (active && D == 3) ? q[i * D + 2] : K.b_def;
-  const double s = rsf::f32::solve32<DAMP, true, false, false>(reinterpret_cast<float *>(lds), K, active, dc, a, b, nullptr, 0);
+  const double s = rsf::f32::solve32<DAMP, true, false>(reinterpret_cast<float *>(lds), K, false, active, dc, a, b, nullptr, 0);
   if (active) ssq[i] = s;
 }
 
@@ -263,18 +256,10 @@ __global__ void __launch_bounds__(kMaxBlock) mcmc_kernel(Consts K, McmcArgs A) {
     // ---- likelihood: forward solve only for in-bounds proposals, MCMC.py:322-324 ----
     const double an = D == 3 ? qn[1] : K.a_def, bn = D == 3 ? qn[2] : K.b_def;
     double ssqn = 0.0;
-    if constexpr (F32) {
-      if (resident) {
-        if (inb) ssqn = rsf::f32::solve32<DAMP, true, false, true>(lds32, K, true, qn[0], an, bn, nullptr, 0);
-      } else {
-        ssqn = rsf::f32::solve32<DAMP, true, false, false>(lds32, K, inb, qn[0], an, bn, nullptr, 0);
-      }
-    } else {
-      if (resident) {
-        if (inb) ssqn = rsf::solve<DAMP, true, false, true>(lds, K, true, qn[0], an, bn, nullptr, 0);
-      } else {
-        ssqn = rsf::solve<DAMP, true, false, false>(lds, K, inb, qn[0], an, bn, nullptr, 0);
-      }
+    // (a wave with no in-bounds lane skips the solve when the tables are resident: no barrier inside)
+    if (!resident || __any(inb)) {
+      if constexpr (F32) ssqn = rsf::f32::solve32<DAMP, true, false>(lds32, K, resident, inb, qn[0], an, bn, nullptr, 0);
+      else ssqn = rsf::solve<DAMP, true, false>(lds, K, resident, inb, qn[0], an, bn, nullptr, 0);
     }
     // ---- accept / reject, MCMC.py:327-333 ----
     bool accept = false;
