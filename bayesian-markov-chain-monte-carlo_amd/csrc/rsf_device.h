@@ -53,9 +53,12 @@ struct Lane {
   double boa;     // b/a
   double tc;      // -mu_ref/a
   double hhd, hd, h6d;  // (h/2)/Dc, h/Dc, (h/6)/Dc : theta increments in x units
-  double c_l1p;   // leading series coefficients kept in VGPRs (a VOP3 takes one SGPR source and the first Horner
-  double c_em1;   //   term has two non-inline constants): log1p 1/7 (wide) or -1/6 (narrow); expm1 1/5040
+  double c_l1p;   // leading series coefficients of the active tier, kept in VGPRs (a VOP3 takes one SGPR source and
+  double c_em1;   //   the first Horner term has two non-inline constants); see set_tier
 };
+
+template <int T>
+__device__ __forceinline__ void set_tier(Lane &L);
 
 __device__ __forceinline__ Lane make_lane(double dc, double a, double b, const Consts &K) {
   Lane L;
@@ -71,9 +74,7 @@ __device__ __forceinline__ Lane make_lane(double dc, double a, double b, const C
   L.hhd = K.hh * L.inv_dc;
   L.hd = K.h * L.inv_dc;
   L.h6d = K.h6 * L.inv_dc;
-  L.c_l1p = 1.0 / 7.0;
-  L.c_em1 = 1.0 / 5040.0;
-  asm volatile("" : "+v"(L.c_l1p), "+v"(L.c_em1));  // opaque: stays a register value, not re-materialised per step
+  set_tier<2>(L);
   return L;
 }
 
@@ -118,53 +119,76 @@ __device__ __forceinline__ void eval_full(double ms, double x, const Lane &L, co
 
 // (w', 1/x') at (ms + dms, x1 = x + dx) from (w, rx) at (ms, x).  With rho = dx/x (= dtheta/theta) and
 // dlt = dmu/a - (b/a) log1p(rho), dmu/a = kia*dms:   w' = w exp(dlt),   1/x' = (1/x)/(1 + rho),
-// by short series — the same function of (ms', x') to rounding inside the guard region:
-//   |dlt| < 2^-6 : expm1 to dlt^7/5040                      (next term < 9e-20)
-//   NARROW |rho| < 2^-9 : log1p to rho^6/6, 1/x' by a 2nd-order start + 1 Newton step (rho^6 < 2^-54)
-//   WIDE   |rho| < 2^-7 : log1p to rho^7/7, 1/x' by a 1st-order start + 2 Newton steps (rho^8 < 2^-56)
+// by short series — the same function of (ms', x') to rounding inside the tier's guard region:
+//   tier     |rho| <   |dlt| <   log1p to     expm1 to       1/x'                              truncation
+//   TIGHT    2^-20     2^-9      rho^2/2      dlt^5/120      1st-order start + 1 Newton step   < 3e-19, rho^4 < 2^-80
+//   NARROW   2^-9      2^-6      rho^6/6      dlt^7/5040     2nd-order start + 1 Newton step   < 1e-19, rho^6 < 2^-54
+//   WIDE     2^-7      2^-6      rho^7/7      dlt^7/5040     1st-order start + 2 Newton steps  < 1e-19, rho^8 < 2^-56
 // Guard tracks the largest |rho| / |dlt| seen since it was last reset.
+enum Tier : int { TIGHT = 0, NARROW = 1, WIDE = 2 };
+
 struct Guard {
   double rho, dlt;
 };
 
-template <bool WIDE>
+// leading series coefficients of a tier (kept in VGPRs, see Lane)
+template <int T>
+__device__ __forceinline__ void set_tier(Lane &L) {
+  L.c_l1p = T == NARROW ? -1.0 / 6.0 : 1.0 / 7.0;  // (TIGHT needs none: 1 - rho/2 has inline constants only)
+  L.c_em1 = T == TIGHT ? 1.0 / 120.0 : 1.0 / 5040.0;
+  asm volatile("" : "+v"(L.c_l1p), "+v"(L.c_em1));  // opaque: stays a register value, not re-materialised per step
+}
+
+template <int T>
 __device__ __forceinline__ void eval_incr(double dms, double dx, double x1, const Lane &L, double w0, double rx0,
                                           double &w, double &rx, Guard &g) {
   const double rho = dx * rx0;
   g.rho = __builtin_fmax(g.rho, __builtin_fabs(rho));
   double p;
-  if (WIDE) {
-    p = fm::hfma(L.c_l1p, rho, -1.0 / 6.0);  // c_l1p = 1/7
-    p = fm::hfma(p, rho, 1.0 / 5.0);
+  if (T == TIGHT) {
+    p = __builtin_fma(rho, -0.5, 1.0);
   } else {
-    p = fm::hfma(L.c_l1p, rho, 1.0 / 5.0);   // c_l1p = -1/6
+    if (T == WIDE) {
+      p = fm::hfma(L.c_l1p, rho, -1.0 / 6.0);
+      p = fm::hfma(p, rho, 1.0 / 5.0);
+    } else {
+      p = fm::hfma(L.c_l1p, rho, 1.0 / 5.0);
+    }
+    p = fm::hfma(p, rho, -1.0 / 4.0);
+    p = fm::hfma(p, rho, 1.0 / 3.0);
+    p = __builtin_fma(p, rho, -0.5);
+    p = __builtin_fma(p, rho, 1.0);
   }
-  p = fm::hfma(p, rho, -1.0 / 4.0);
-  p = fm::hfma(p, rho, 1.0 / 3.0);
-  p = __builtin_fma(p, rho, -0.5);
-  p = __builtin_fma(p, rho, 1.0);
   const double dlt = __builtin_fma(-L.boa, p * rho, dms * L.kia);
   g.dlt = __builtin_fmax(g.dlt, __builtin_fabs(dlt));
-  double e = fm::hfma(L.c_em1, dlt, 1.0 / 720.0);
-  e = fm::hfma(e, dlt, 1.0 / 120.0);
+  double e;
+  if (T == TIGHT) {
+    e = L.c_em1;
+  } else {
+    e = fm::hfma(L.c_em1, dlt, 1.0 / 720.0);
+    e = fm::hfma(e, dlt, 1.0 / 120.0);
+  }
   e = fm::hfma(e, dlt, 1.0 / 24.0);
   e = fm::hfma(e, dlt, 1.0 / 6.0);
   e = __builtin_fma(e, dlt, 0.5);
   e = __builtin_fma(e, dlt, 1.0);
   w = __builtin_fma(w0, e * dlt, w0);
-  if (WIDE) {
+  if (T == WIDE) {
     rx = __builtin_fma(-rho, rx0, rx0);
     rx = __builtin_fma(rx, __builtin_fma(-x1, rx, 1.0), rx);
     rx = __builtin_fma(rx, __builtin_fma(-x1, rx, 1.0), rx);
-  } else {
+  } else if (T == NARROW) {
     rx = __builtin_fma(rx0, __builtin_fma(rho, rho, -rho), rx0);
+    rx = __builtin_fma(rx, __builtin_fma(-x1, rx, 1.0), rx);
+  } else {
+    rx = __builtin_fma(-rho, rx0, rx0);
     rx = __builtin_fma(rx, __builtin_fma(-x1, rx, 1.0), rx);
   }
 }
 
-template <bool WIDE>
-__device__ __forceinline__ bool guard_ok(const Guard &g) {
-  return (g.rho < (WIDE ? 0x1.0p-7 : 0x1.0p-9)) && (g.dlt < 0x1.0p-6);  // false for Inf; NaN passes through
+template <int T>
+__device__ __forceinline__ bool guard_ok(const Guard &g) {  // false for Inf; NaN passes through
+  return (g.rho < (T == WIDE ? 0x1.0p-7 : (T == NARROW ? 0x1.0p-9 : 0x1.0p-20))) && (g.dlt < (T == TIGHT ? 0x1.0p-9 : 0x1.0p-6));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -207,24 +231,24 @@ __device__ __forceinline__ void rk4_cold(State &s, double vl0, double vlm, doubl
   s.V = __builtin_fma(K.h6, s2, s.V);
 }
 
-template <bool DAMP, bool WIDE>
+template <bool DAMP, int T>
 __device__ __forceinline__ void rk4_fast(State &s, double vl0, double vlm, double vl1, const Lane &L,
                                          const Consts &K, Guard &g) {
   double a0, a1, a2, b0, b1, b2, c0, c1, c2, e0, e1, e2, w, rx;
   rhs_tail<DAMP>(s.w, s.rx, s.x, vl0, L, K, a0, a1, a2);
   double dx = L.hhd * a1;
-  eval_incr<WIDE>(K.hh * a0, dx, s.x + dx, L, s.w, s.rx, w, rx, g);
+  eval_incr<T>(K.hh * a0, dx, s.x + dx, L, s.w, s.rx, w, rx, g);
   rhs_tail<DAMP>(w, rx, s.x + dx, vlm, L, K, b0, b1, b2);
   dx = L.hhd * b1;
-  eval_incr<WIDE>(K.hh * b0, dx, s.x + dx, L, s.w, s.rx, w, rx, g);
+  eval_incr<T>(K.hh * b0, dx, s.x + dx, L, s.w, s.rx, w, rx, g);
   rhs_tail<DAMP>(w, rx, s.x + dx, vlm, L, K, c0, c1, c2);
   dx = L.hd * c1;
-  eval_incr<WIDE>(K.h * c0, dx, s.x + dx, L, s.w, s.rx, w, rx, g);
+  eval_incr<T>(K.h * c0, dx, s.x + dx, L, s.w, s.rx, w, rx, g);
   rhs_tail<DAMP>(w, rx, s.x + dx, vl1, L, K, e0, e1, e2);
   const double dms = K.h6 * (a0 + 2.0 * b0 + 2.0 * c0 + e0);
   dx = L.h6d * (a1 + 2.0 * b1 + 2.0 * c1 + e1);
   const double x1 = s.x + dx;
-  eval_incr<WIDE>(dms, dx, x1, L, s.w, s.rx, w, rx, g);
+  eval_incr<T>(dms, dx, x1, L, s.w, s.rx, w, rx, g);
   s.ms = s.ms + dms;
   s.x = x1;
   s.V = s.V + K.h6 * (a2 + 2.0 * b2 + 2.0 * c2 + e2);
@@ -243,8 +267,8 @@ __device__ __forceinline__ void rk4_step(State &s, bool resync, double vl0, doub
   if (resync) eval_full(s.ms, s.x, L, K, s.w, s.rx);
   const State save = s;
   Guard g = {0.0, 0.0};
-  rk4_fast<DAMP, true>(s, vl0, vlm, vl1, L, K, g);
-  if (__builtin_expect(!guard_ok<true>(g), 0)) {  // an increment too large (or Inf; NaN passes through): cold path
+  rk4_fast<DAMP, WIDE>(s, vl0, vlm, vl1, L, K, g);
+  if (__builtin_expect(!guard_ok<WIDE>(g), 0)) {  // an increment too large (or Inf; NaN passes through): cold path
     s = save;
     rk4_cold<DAMP>(s, vl0, vlm, vl1, L, K);
     eval_full(s.ms, s.x, L, K, s.w, s.rx);
@@ -283,26 +307,24 @@ __device__ __forceinline__ void stage_chunk(double *lds, const Consts &K, int k0
 
 // One step per output sample (the BASELINE configs): steps go in PAIRS through straight-line code, so loop
 // control, the resync test, the increment guard and the LDS address are paid once per two steps and no register
-// copies are needed to rotate the state.  A failed guard redoes the pair from `save` with full evaluations; an
-// odd last step takes the full-evaluation path as well.
-template <bool DAMP, bool WANT_SSQ, bool WANT_ACC, bool WIDE>
-__device__ __forceinline__ void integrate_pairs(const double *lds, const double *ld, const Consts &K, Lane L, int k0,
-                                                int kn, State &s, double &ssq, double *acc_out, int64_t stride) {
-  if (!WIDE) {
-    L.c_l1p = -1.0 / 6.0;
-    asm volatile("" : "+v"(L.c_l1p));
-  }
-  int kk = 0;
+// copies are needed to rotate the state.  A failed guard redoes the pair from `save` with full evaluations and,
+// for the TIGHT and NARROW tiers, hands the rest of the chunk to the next wider tier (wave-uniform decision).
+// Returns the index of the first sample not yet integrated.
+template <bool DAMP, bool WANT_SSQ, bool WANT_ACC, int T>
+__device__ __forceinline__ int integrate_pairs(const double *lds, const double *ld, const Consts &K, Lane L, int k0,
+                                               int kk, int kn, State &s, double &ssq, double *acc_out, int64_t stride) {
+  set_tier<T>(L);
   for (; kk + 2 <= kn; kk += 2) {
     const double *v = lds + 2 * kk;
     const double dd0 = ld[kk], dd1 = ld[kk + 1];
     if ((kk & (RSF_RESYNC - 1)) == 0) eval_full(s.ms, s.x, L, K, s.w, s.rx);
     const State save = s;
     Guard g = {0.0, 0.0};
-    rk4_fast<DAMP, WIDE>(s, v[0], v[1], v[2], L, K, g);
+    rk4_fast<DAMP, T>(s, v[0], v[1], v[2], L, K, g);
     double vmid = s.V;
-    rk4_fast<DAMP, WIDE>(s, v[2], v[3], v[4], L, K, g);
-    if (__builtin_expect(!guard_ok<WIDE>(g), 0)) {
+    rk4_fast<DAMP, T>(s, v[2], v[3], v[4], L, K, g);
+    const bool bad = !guard_ok<T>(g);
+    if (__builtin_expect(bad, 0)) {
       s = save;
       rk4_cold<DAMP>(s, v[0], v[1], v[2], L, K);
       vmid = s.V;
@@ -319,19 +341,9 @@ __device__ __forceinline__ void integrate_pairs(const double *lds, const double 
       ssq += r0 * r0;
       ssq += r1 * r1;
     }
+    if (T != WIDE && __any(bad)) return kk + 2;
   }
-  if (kk < kn) {
-    const double *v = lds + 2 * kk;
-    const double vprev = s.V;
-    rk4_cold<DAMP>(s, v[0], v[1], v[2], L, K);
-    eval_full(s.ms, s.x, L, K, s.w, s.rx);
-    const double ak = (s.V - vprev) * K.inv_dt;
-    if (WANT_ACC) acc_out[(int64_t)(k0 + kk) * stride] = ak;
-    if (WANT_SSQ) {
-      const double r = ak - ld[kk];
-      ssq += r * r;
-    }
-  }
+  return kk;
 }
 
 // Integrate kn output intervals from the staged chunk.  Accumulates the sum of squares
@@ -342,15 +354,31 @@ __device__ __forceinline__ void integrate_chunk(const double *lds, const Consts 
   const double *ld = lds + lds_data_offset(K);
 #ifndef RSF_NO_INCREMENTAL
   if (K.S == 1) {
-    // wave-uniform choice of the series variant from a bound on |dth/th| (<= 4 h / Dc while v <= 2 V_ref);
-    // either variant is exact to rounding inside its guard, so this is a speed decision only
+    // Wave-uniform choice of the starting tier — a speed decision only: every tier is exact to rounding inside
+    // its guard, and a tier whose guard trips redoes that pair in full and hands over to the next wider one.
+    // TIGHT is tried whenever the mu increment allows it (|V_l - v| <~ 1.2): theta tracks its steady state
+    // closely (|dtheta/theta| ~ 1e-7 per stage at Dc ~ 1000, h = 0.1), which no a-priori bound captures.
 #ifdef RSF_FORCE_NARROW
-    const bool wide = false;
+    const int tier = NARROW;
 #else
-    const bool wide = __any(!(4.0 * K.h * L.inv_dc < 0x1.0p-9));
+    const int tier = !__any(!(1.2 * K.h * L.kia < 0x1.0p-9)) ? TIGHT : (!__any(!(4.0 * K.h * L.inv_dc < 0x1.0p-9)) ? NARROW : WIDE);
 #endif
-    if (wide) integrate_pairs<DAMP, WANT_SSQ, WANT_ACC, true>(lds, ld, K, L, k0, kn, s, ssq, acc_out, stride);
-    else integrate_pairs<DAMP, WANT_SSQ, WANT_ACC, false>(lds, ld, K, L, k0, kn, s, ssq, acc_out, stride);
+    int kk = 0;
+    if (tier == TIGHT) kk = integrate_pairs<DAMP, WANT_SSQ, WANT_ACC, TIGHT>(lds, ld, K, L, k0, kk, kn, s, ssq, acc_out, stride);
+    if (tier <= NARROW) kk = integrate_pairs<DAMP, WANT_SSQ, WANT_ACC, NARROW>(lds, ld, K, L, k0, kk, kn, s, ssq, acc_out, stride);
+    kk = integrate_pairs<DAMP, WANT_SSQ, WANT_ACC, WIDE>(lds, ld, K, L, k0, kk, kn, s, ssq, acc_out, stride);
+    if (kk < kn) {  // odd last sample of the chunk: one full-evaluation step
+      const double *v = lds + 2 * kk;
+      const double vprev = s.V;
+      rk4_cold<DAMP>(s, v[0], v[1], v[2], L, K);
+      eval_full(s.ms, s.x, L, K, s.w, s.rx);
+      const double ak = (s.V - vprev) * K.inv_dt;
+      if (WANT_ACC) acc_out[(int64_t)(k0 + kk) * stride] = ak;
+      if (WANT_SSQ) {
+        const double r = ak - ld[kk];
+        ssq += r * r;
+      }
+    }
     return;
   }
 #endif
