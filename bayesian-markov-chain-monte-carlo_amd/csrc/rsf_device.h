@@ -200,11 +200,11 @@ __device__ __forceinline__ bool guard_ok(const Guard &g) {  // false for Inf; Na
 // instruction, nop and branch costs a full ~5-cycle issue slot (tools/microbench_fp64.hip).
 // The largest relative increment of the step is checked ONCE; if a lane exceeded 2^-9 (stiff
 // small-Dc proposals) the step is redone from the saved start point with full evaluations
-// (rk4_cold).  Every RSF_RESYNC steps (w, 1/th) are recomputed in full so rounding in the
+// (rk4_cold).  Every RSF_RESYNC steps (w, 1/x) are recomputed in full so rounding in the
 // incremental products cannot accumulate (1/th is self-correcting through its Newton steps).
 // ---------------------------------------------------------------------------------------------
 #ifndef RSF_RESYNC
-#define RSF_RESYNC 32
+#define RSF_RESYNC 128
 #endif
 
 template <bool DAMP>
