@@ -324,12 +324,15 @@ __device__ __forceinline__ int integrate_pairs(const double *lds, const double *
     double vmid = s.V;
     rk4_fast<DAMP, T>(s, v[2], v[3], v[4], L, K, g);
     const bool bad = !guard_ok<T>(g);
-    if (__builtin_expect(bad, 0)) {
-      s = save;
-      rk4_cold<DAMP>(s, v[0], v[1], v[2], L, K);
-      vmid = s.V;
-      rk4_cold<DAMP>(s, v[2], v[3], v[4], L, K);
-      eval_full(s.ms, s.x, L, K, s.w, s.rx);
+    const unsigned long long badmask = __builtin_amdgcn_ballot_w64(bad);  // wave-uniform, straight from the compares
+    if (__builtin_expect(badmask != 0, 0)) {  // scalar branch: the hot path carries no exec-mask bookkeeping
+      if (bad) {
+        s = save;
+        rk4_cold<DAMP>(s, v[0], v[1], v[2], L, K);
+        vmid = s.V;
+        rk4_cold<DAMP>(s, v[2], v[3], v[4], L, K);
+        eval_full(s.ms, s.x, L, K, s.w, s.rx);
+      }
     }
     const double ak0 = (vmid - save.V) * K.inv_dt, ak1 = (s.V - vmid) * K.inv_dt;  // RateStateModel.py:388
     if (WANT_ACC) {
@@ -341,7 +344,7 @@ __device__ __forceinline__ int integrate_pairs(const double *lds, const double *
       ssq += r0 * r0;
       ssq += r1 * r1;
     }
-    if (T != WIDE && __any(bad)) return kk + 2;
+    if (T != WIDE && badmask != 0) return kk + 2;
   }
   return kk;
 }
