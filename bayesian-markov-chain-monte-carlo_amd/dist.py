@@ -52,6 +52,27 @@ def allgather_pool(local, group=None):
     return out.view((world,) + tuple(local.shape))
 
 
+def allreduce_summary(local, group=None, device=None):
+    """Summary path: combine per-rank `Engine.pool_summary` dicts {n, mean, var, min, max} into the
+    global moments with three tiny all-reduces (SUM of n / sum / centred sum of squares, MIN, MAX) instead of
+    materialising the pooled samples on every rank.  Returns the same dict for the union of all ranks' draws."""
+    import torch
+    import torch.distributed as dist
+
+    n, mean, var = float(local["n"]), float(local["mean"]), float(local["var"])
+    # sums about zero are combined in float64; the centred second moment is rebuilt with the parallel formula
+    t = torch.tensor([n, n * mean], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    N, gmean = float(t[0]), float(t[1] / t[0])
+    m2 = torch.tensor([var * (n - 1.0) + n * (mean - gmean) ** 2], dtype=torch.float64, device=device)
+    dist.all_reduce(m2, op=dist.ReduceOp.SUM, group=group)
+    lo = torch.tensor([float(local["min"])], dtype=torch.float64, device=device)
+    hi = torch.tensor([float(local["max"])], dtype=torch.float64, device=device)
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=group)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=group)
+    return dict(n=N, mean=gmean, var=float(m2[0]) / (N - 1.0) if N > 1 else 0.0, min=float(lo[0]), max=float(hi[0]))
+
+
 def pool_to_chain_major(pool):
     """(G, n_keep, C_local, d) → (n_keep, G*C_local, d): global chain id = g*C_local + c."""
     G, n, C, d = pool.shape

@@ -77,7 +77,14 @@ def cpu_baseline(model, data, target_s=12.0):
         e.mcmc_run(iters, traces=("q", "std2"))
         wall = time.perf_counter() - t0
     nsteps = model.num_tsteps
-    return dict(value=chains * iters * nsteps / wall, unit="ODE-steps*chains/s", cores=cores, kind="port",
+    with pkg.Engine(lib=lib, cpu_threads=1) as e:  # per-core figure: a short single-thread run
+        e.set_model(model, 1)
+        e.mcmc_init(np.full((8, 1), 1000.0), data, [0.0], [1.0e4], seed=2025, prior_len=3)
+        e.mcmc_run(1, traces=False)
+        t0 = time.perf_counter()
+        e.mcmc_run(40, traces=False)
+        one_core = 8 * 40 * nsteps / (time.perf_counter() - t0)
+    return dict(value=chains * iters * nsteps / wall, unit="ODE-steps*chains/s", cores=cores, kind="port", single_thread_value=one_core,
                 sample=f"{chains} chains x {iters} proposals x nsteps {nsteps} ({nout - 1} RK4 steps each), "
                        f"oracle/librsf_oracle.so with OpenMP over chains, {wall:.1f} s")
 

@@ -53,6 +53,12 @@ def _worker(rank, port, out_dir):
     pool, stats = rdist.run_sharded(lambda: pkg.Engine(lib=lib, cpu_threads=2), model, 1, data, q0, [0.0], [1e4], N_ITERS, NBURN,
                                     seed=77, mcmc_kwargs=dict(prior_len=3))
     np.save(os.path.join(out_dir, f"pool_{rank}.npy"), pool.numpy())
+    # summary path: per-rank moments of the local shard, combined with all-reduces
+    per = C // WORLD
+    with pkg.Engine(lib=lib) as e:
+        local = e.pool_summary(pool[:, rank * per:(rank + 1) * per].contiguous().numpy())
+    glob = rdist.allreduce_summary(local)
+    np.save(os.path.join(out_dir, f"summary_{rank}.npy"), np.array([glob[k] for k in ("n", "mean", "var", "min", "max")]))
     assert stats["iters_done"] == N_ITERS
     dist.barrier()
     dist.destroy_process_group()
@@ -79,5 +85,8 @@ def test_two_rank_pool_equals_single_process(pkg, oracle_lib, oracle_mod, tmp_pa
         e.set_model(model, 1)
         e.mcmc_init(q0, data, [0.0], [1e4], seed=77, chain_offset=0, prior_len=3)
         tq, _, _ = e.mcmc_run(N_ITERS, traces=("q",))
+    x = pools[0].ravel()
+    for r in range(WORLD):
+        np.testing.assert_allclose(np.load(tmp_path / f"summary_{r}.npy"), [x.size, x.mean(), x.var(ddof=1), x.min(), x.max()], rtol=1e-12)
     assert pools[0].shape == (N_ITERS - NBURN + 1, C, 1)
     np.testing.assert_array_equal(pools[0], tq[NBURN - 1:])
