@@ -55,6 +55,18 @@ def synthetic_problem(nsteps):
     return model, data
 
 
+def effective_cpus():
+    """Host threads this process may really use: the affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = max(1, min(n, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baseline(model, data, target_s=12.0):
     """Time the CPU restatement on a bounded sample of the same workload (all host cores)."""
     import bayesian_markov_chain_monte_carlo_amd as pkg
@@ -63,7 +75,7 @@ def cpu_baseline(model, data, target_s=12.0):
     import rsf_oracle
 
     lib = pkg._abi.bind(ctypes.CDLL(rsf_oracle.lib_path()))
-    cores = len(os.sched_getaffinity(0))
+    cores = effective_cpus()
     chains = 16 * cores
     with pkg.Engine(lib=lib, cpu_threads=cores) as e:
         nout = e.set_model(model, 1)

@@ -201,6 +201,15 @@ def test_edge_cases_and_call_order(pkg, cpu_engine, oracle_mod):
                 ref = (s, a)
             np.testing.assert_array_equal(s, ref[0])
             np.testing.assert_array_equal(a, ref[1])
+    ref = None
+    for block in (64, 256):  # ... including the fused sampler kernel
+        with pkg.Engine(mem="host", block_threads=block) as e:
+            e.set_model(m, 1)
+            e.mcmc_init(np.full((200, 1), 1000.0), data, [0.0], [1e4], seed=3, prior_len=3)
+            out = e.mcmc_run(8)
+            ref = ref or out
+            for k in range(3):
+                np.testing.assert_array_equal(out[k], ref[k])
     with pytest.raises(pkg._abi.RsfError):
         pkg.Engine(mem="host", block_threads=96)
     with pkg.Engine(mem="host") as e:
