@@ -1,0 +1,43 @@
+/* abi_smoke.c — plain-C caller of include/rsf_abi.h (test-only).  Mirrors INTEGRATION.md section 3:
+ * one forward solve + SSq for three Dc values, then a short fused MCMC run; prints the numbers so the
+ * Python test can compare them with the same calls made through ctypes.
+ *   gcc abi_smoke.c -I../../include -L<csrc> -lrsf_hip -L/opt/rocm/lib -lamdhip64 -lm */
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+#include "rsf_abi.h"
+
+#define CHECK(x) do { if ((x) != RSF_OK) { fprintf(stderr, "%s failed: %s\n", #x, rsf_last_error()); return 1; } } while (0)
+
+int main(void) {
+  rsf_ctx *ctx;
+  rsf_config cfg = {sizeof cfg, RSF_ABI_VERSION, -1, RSF_MEM_HOST, NULL, 0, 0};
+  CHECK(rsf_create(&cfg, &ctx));
+  rsf_model m = {sizeof m, RSF_FLAG_RADIATION_DAMPING, 500, 1, 0.0, 50.0, 0.6, 1.0, 1e-7, 0.6, 0.011, 0.014};
+  CHECK(rsf_set_model(ctx, &m));
+  int32_t nout;
+  CHECK(rsf_model_nout(ctx, &nout));
+  double dc[3] = {500.0, 1000.0, 2000.0}, ssq[3];
+  double *acc = malloc(sizeof(double) * nout * 3), *data = malloc(sizeof(double) * nout);
+  CHECK(rsf_forward_batch(ctx, 3, dc, NULL, NULL, NULL, NULL, acc));
+  for (int k = 0; k < nout; ++k) data[k] = acc[k * 3 + 1] * (1.0 + 0.3 * sin(0.7 * k)); /* deterministic "noise" */
+  CHECK(rsf_forward_batch(ctx, 3, dc, NULL, NULL, data, ssq, NULL));
+  printf("nout %d\nssq %.17g %.17g %.17g\n", nout, ssq[0], ssq[1], ssq[2]);
+  enum { C = 64, ITERS = 10 };
+  double q0[C], tq[ITERS * C], ts[ITERS * C];
+  for (int i = 0; i < C; ++i) q0[i] = 1000.0;
+  rsf_mcmc_config mc = {sizeof mc, 1, C, 0, 2025, 0.01, 3, RSF_ADAPT_NONE, 10, 0, 1e-6, {0.0}, {1e4}};
+  CHECK(rsf_mcmc_init(ctx, &mc, q0, data));
+  CHECK(rsf_mcmc_run(ctx, ITERS, tq, ts, NULL));
+  int64_t acc_n, eval_n, nonfinite, done;
+  CHECK(rsf_mcmc_stats(ctx, &acc_n, &eval_n, &nonfinite, &done));
+  double mean = 0;
+  for (int i = 0; i < C; ++i) mean += tq[(ITERS - 1) * C + i];
+  printf("mcmc %.17g %.17g %lld %lld %lld %lld\n", mean / C, ts[(ITERS - 1) * C], (long long)acc_n, (long long)eval_n,
+         (long long)nonfinite, (long long)done);
+  printf("backend %s version %d devices %d\n", rsf_backend(), rsf_version(), rsf_device_count());
+  CHECK(rsf_destroy(ctx));
+  free(acc); free(data);
+  return 0;
+}

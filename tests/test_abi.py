@@ -104,3 +104,20 @@ def test_engine_checks_shapes(cpu_engine, oracle_mod):
         cpu_engine.mcmc_init([[1000.0]], np.zeros(10), [0.0], [1e4])
     ssq, acc = cpu_engine.forward(np.empty(0), want_acc=True)
     assert acc.shape == (500, 0)
+
+
+def test_header_compiles_as_c_and_runs_against_the_oracle(oracle_mod, tmp_path):
+    """The same plain-C program the GPU suite links against librsf_hip.so (tests/c/abi_smoke.c) — here against the
+    CPU oracle: the header is valid C and both libraries really share one ABI."""
+    import subprocess
+
+    exe = tmp_path / "abi_smoke_cpu"
+    odir = os.path.dirname(oracle_mod.lib_path())
+    subprocess.check_call(["gcc", "-std=c11", "-Wall", "-Werror", "-O1", "-o", str(exe), os.path.join(ROOT, "tests", "c", "abi_smoke.c"),
+                           "-I" + os.path.join(ROOT, "include"), "-L" + odir, "-lrsf_oracle", "-lm", "-Wl,-rpath," + odir])
+    out = subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split("\n")
+    assert out[0] == "nout 500" and out[3] == "backend oracle-cpu version 1 devices 0"
+    ssq = np.array(out[1].split()[1:], dtype=np.float64)
+    assert ssq[1] < ssq[0] and ssq[1] < ssq[2] and np.isfinite(ssq).all()
+    mean, std2, acc, ev, nonfinite, done = out[2].split()[1:]
+    assert 800 < float(mean) < 1200 and float(std2) > 0 and int(ev) == 640 and int(done) == 10 and int(nonfinite) == 0

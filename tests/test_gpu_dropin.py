@@ -102,3 +102,35 @@ def test_integration_md_binding_stub_works(pkg, golden):
         want, _ = e.forward(g["qgrid"], data=g["data"], want_ssq=True, want_acc=False)
     np.testing.assert_array_equal(got, want)
     np.testing.assert_allclose(got[4:], g["ssq"][4:], rtol=1e-3)  # and it is the reference's SSq (Tier 2, S = 1)
+
+
+def test_plain_c_caller(pkg, tmp_path):
+    """a C program linked against librsf_hip.so and the SYSTEM HIP runtime (the library
+    carries no DT_NEEDED on a runtime) gets the same numbers as the ctypes path running on torch's bundled runtime."""
+    import subprocess
+
+    from conftest import ROOT
+
+    exe = tmp_path / "abi_smoke"
+    csrc = os.path.dirname(pkg._abi.LIB_PATH)
+    subprocess.check_call(["gcc", "-O1", "-o", str(exe), os.path.join(ROOT, "tests", "c", "abi_smoke.c"),
+                           "-I" + os.path.join(ROOT, "include"), "-L" + csrc, "-lrsf_hip", "-L/opt/rocm/lib", "-lamdhip64", "-lm",
+                           "-Wl,-rpath," + csrc, "-Wl,-rpath,/opt/rocm/lib"])
+    out = subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split("\n")
+    assert out[0] == "nout 500" and out[3].startswith("backend hip-gfx950 version 1 devices")
+    c_ssq = np.array(out[1].split()[1:], dtype=np.float64)
+    c_mcmc = out[2].split()[1:]
+    model = pkg.RateStateModel(500)
+    with pkg.Engine(mem="host") as e:
+        e.set_model(model, 1)
+        dc = np.array([500.0, 1000.0, 2000.0])
+        _, acc = e.forward(dc)
+        data = acc[:, 1] * (1.0 + 0.3 * np.sin(0.7 * np.arange(500)))
+        ssq, _ = e.forward(dc, data=data, want_ssq=True, want_acc=False)
+        np.testing.assert_allclose(c_ssq, ssq, rtol=1e-13)  # sin() of libm vs NumPy may differ in the last bit
+        e.mcmc_init(np.full((64, 1), 1000.0), data, [0.0], [1e4], seed=2025, prior_len=3)
+        tq, ts, _ = e.mcmc_run(10)
+        st = e.stats()
+    np.testing.assert_allclose(float(c_mcmc[0]), tq[-1, :, 0].mean(), rtol=1e-9)
+    np.testing.assert_allclose(float(c_mcmc[1]), ts[-1, 0], rtol=1e-9)
+    assert [int(v) for v in c_mcmc[2:]] == [st["accepted"], st["evaluated"], st["nonfinite"], st["iters_done"]]
