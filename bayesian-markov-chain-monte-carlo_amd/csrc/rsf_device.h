@@ -305,19 +305,48 @@ __device__ __forceinline__ void stage_chunk(double *lds, const Consts &K, int k0
   __syncthreads();
 }
 
-// One step per output sample (the BASELINE configs): steps go in PAIRS through straight-line code, so loop
-// control, the resync test, the increment guard and the LDS address are paid once per two steps and no register
-// copies are needed to rotate the state.  A failed guard redoes the pair from `save` with full evaluations and,
-// for the TIGHT and NARROW tiers, hands the rest of the chunk to the next wider tier (wave-uniform decision).
-// Returns the index of the first sample not yet integrated.
-template <bool DAMP, bool WANT_SSQ, bool WANT_ACC, int T>
-__device__ __forceinline__ int integrate_pairs(const double *lds, const double *ld, const Consts &K, Lane L, int k0,
-                                               int kk, int kn, State &s, double &ssq, double *acc_out, int64_t stride) {
+// RK4 steps go in PAIRS through straight-line code, so loop control, the resync test, the increment guard and the
+// LDS address are paid once per two steps and no register copies are needed to rotate the state.  A failed guard
+// redoes the pair from `save` with full evaluations and, for the TIGHT and NARROW tiers, hands the rest of the
+// chunk to the next wider tier (wave-uniform decision).  S1: one step per output sample (the BASELINE configs),
+// both steps of a pair emit a sample; otherwise a sample is emitted every K.S steps (wave-uniform phase counter).
+struct Emit {            // output bookkeeping of a chunk
+  int ko;                // next output sample of the chunk (0 .. kn-1)
+  int phase;             // RK4 steps since the last emitted sample (S > 1 only)
+  double vprev;          // V at the last emitted sample
+};
+
+// acceleration sample ko of the chunk from the velocities at its two ends (RateStateModel.py:388) + SSq term;
+// `obs` is the observation at that sample (read from LDS by the caller, early, so its latency is hidden)
+template <bool WANT_SSQ, bool WANT_ACC>
+__device__ __forceinline__ void emit_at(double vnow, double vprev, int ko, double obs, const Consts &K, int k0,
+                                        double &ssq, double *acc_out, int64_t stride) {
+  const double ak = (vnow - vprev) * K.inv_dt;
+  if (WANT_ACC) acc_out[(int64_t)(k0 + ko) * stride] = ak;
+  if (WANT_SSQ) {
+    const double r = ak - obs;
+    ssq = __builtin_fma(r, r, ssq);
+  }
+}
+
+template <bool WANT_SSQ, bool WANT_ACC>
+__device__ __forceinline__ void emit_sample(double vnow, Emit &em, double obs, const Consts &K, int k0, double &ssq,
+                                            double *acc_out, int64_t stride) {
+  emit_at<WANT_SSQ, WANT_ACC>(vnow, em.vprev, em.ko, obs, K, k0, ssq, acc_out, stride);
+  em.vprev = vnow;
+  ++em.ko;
+}
+
+// integrates RK4 steps [r, nsteps) of the chunk two at a time; returns the first step not yet integrated
+template <bool DAMP, bool WANT_SSQ, bool WANT_ACC, int T, bool S1>
+__device__ __forceinline__ int integrate_pairs(const double *lds, const double *ld, const Consts &K, Lane L, int k0, int r,
+                                               int nsteps, State &s, Emit &em, double &ssq, double *acc_out, int64_t stride) {
   set_tier<T>(L);
-  for (; kk + 2 <= kn; kk += 2) {
-    const double *v = lds + 2 * kk;
-    const double dd0 = ld[kk], dd1 = ld[kk + 1];
-    if ((kk & (RSF_RESYNC - 1)) == 0) eval_full(s.ms, s.x, L, K, s.w, s.rx);
+  for (; r + 2 <= nsteps; r += 2) {
+    const double *v = lds + 2 * r;
+    // observations this pair can complete, read before the arithmetic (S > 1: at most one sample per pair)
+    const double obs0 = WANT_SSQ ? ld[S1 ? r : em.ko] : 0.0, obs1 = (WANT_SSQ && S1) ? ld[r + 1] : 0.0;
+    if ((r & (RSF_RESYNC - 1)) == 0) eval_full(s.ms, s.x, L, K, s.w, s.rx);
     const State save = s;
     Guard g = {0.0, 0.0};
     rk4_fast<DAMP, T>(s, v[0], v[1], v[2], L, K, g);
@@ -334,19 +363,44 @@ __device__ __forceinline__ int integrate_pairs(const double *lds, const double *
         eval_full(s.ms, s.x, L, K, s.w, s.rx);
       }
     }
-    const double ak0 = (vmid - save.V) * K.inv_dt, ak1 = (s.V - vmid) * K.inv_dt;  // RateStateModel.py:388
-    if (WANT_ACC) {
-      acc_out[(int64_t)(k0 + kk) * stride] = ak0;
-      acc_out[(int64_t)(k0 + kk + 1) * stride] = ak1;
+    if (S1) {  // sample index == step index: no bookkeeping
+      emit_at<WANT_SSQ, WANT_ACC>(vmid, save.V, r, obs0, K, k0, ssq, acc_out, stride);
+      emit_at<WANT_SSQ, WANT_ACC>(s.V, vmid, r + 1, obs1, K, k0, ssq, acc_out, stride);
+    } else {
+      if (++em.phase == K.S) { em.phase = 0; emit_sample<WANT_SSQ, WANT_ACC>(vmid, em, obs0, K, k0, ssq, acc_out, stride); }
+      if (++em.phase == K.S) { em.phase = 0; emit_sample<WANT_SSQ, WANT_ACC>(s.V, em, obs0, K, k0, ssq, acc_out, stride); }
     }
-    if (WANT_SSQ) {
-      const double r0 = ak0 - dd0, r1 = ak1 - dd1;
-      ssq += r0 * r0;
-      ssq += r1 * r1;
-    }
-    if (T != WIDE && badmask != 0) return kk + 2;
+    if (T != WIDE && badmask != 0) return r + 2;
   }
-  return kk;
+  return r;
+}
+
+template <bool DAMP, bool WANT_SSQ, bool WANT_ACC, bool S1>
+__device__ __forceinline__ void integrate_tiers(const double *lds, const double *ld, const Consts &K, const Lane &L, int k0,
+                                                int kn, State &s, double &ssq, double *acc_out, int64_t stride) {
+  // Wave-uniform choice of the starting tier — a speed decision only: every tier is exact to rounding inside
+  // its guard, and a tier whose guard trips redoes that pair in full and hands over to the next wider one.
+  // TIGHT is tried whenever the mu increment allows it (|V_l - v| <~ 1.2): theta tracks its steady state
+  // closely (|dtheta/theta| ~ 1e-7 per stage at Dc ~ 1000, h = 0.1), which no a-priori bound captures.
+#ifdef RSF_FORCE_NARROW
+  const int tier = NARROW;
+#else
+  const int tier = !__any(!(1.2 * K.h * L.kia < 0x1.0p-9)) ? TIGHT : (!__any(!(4.0 * K.h * L.inv_dc < 0x1.0p-9)) ? NARROW : WIDE);
+#endif
+  const int nsteps = S1 ? kn : K.S * kn;
+  Emit em = {0, 0, s.V};
+  int r = 0;
+  if (tier == TIGHT) r = integrate_pairs<DAMP, WANT_SSQ, WANT_ACC, TIGHT, S1>(lds, ld, K, L, k0, r, nsteps, s, em, ssq, acc_out, stride);
+  if (tier <= NARROW) r = integrate_pairs<DAMP, WANT_SSQ, WANT_ACC, NARROW, S1>(lds, ld, K, L, k0, r, nsteps, s, em, ssq, acc_out, stride);
+  r = integrate_pairs<DAMP, WANT_SSQ, WANT_ACC, WIDE, S1>(lds, ld, K, L, k0, r, nsteps, s, em, ssq, acc_out, stride);
+  if (r < nsteps) {  // odd last step of the chunk: one full-evaluation step (it always completes a sample)
+    const double *v = lds + 2 * r;
+    const double vprev = S1 ? s.V : em.vprev;
+    const double obs = WANT_SSQ ? ld[kn - 1] : 0.0;
+    rk4_cold<DAMP>(s, v[0], v[1], v[2], L, K);
+    eval_full(s.ms, s.x, L, K, s.w, s.rx);
+    emit_at<WANT_SSQ, WANT_ACC>(s.V, vprev, kn - 1, obs, K, k0, ssq, acc_out, stride);
+  }
 }
 
 // Integrate kn output intervals from the staged chunk.  Accumulates the sum of squares
@@ -357,34 +411,15 @@ __device__ __forceinline__ void integrate_chunk(const double *lds, const Consts 
   const double *ld = lds + lds_data_offset(K);
 #ifndef RSF_NO_INCREMENTAL
   if (K.S == 1) {
-    // Wave-uniform choice of the starting tier — a speed decision only: every tier is exact to rounding inside
-    // its guard, and a tier whose guard trips redoes that pair in full and hands over to the next wider one.
-    // TIGHT is tried whenever the mu increment allows it (|V_l - v| <~ 1.2): theta tracks its steady state
-    // closely (|dtheta/theta| ~ 1e-7 per stage at Dc ~ 1000, h = 0.1), which no a-priori bound captures.
-#ifdef RSF_FORCE_NARROW
-    const int tier = NARROW;
-#else
-    const int tier = !__any(!(1.2 * K.h * L.kia < 0x1.0p-9)) ? TIGHT : (!__any(!(4.0 * K.h * L.inv_dc < 0x1.0p-9)) ? NARROW : WIDE);
-#endif
-    int kk = 0;
-    if (tier == TIGHT) kk = integrate_pairs<DAMP, WANT_SSQ, WANT_ACC, TIGHT>(lds, ld, K, L, k0, kk, kn, s, ssq, acc_out, stride);
-    if (tier <= NARROW) kk = integrate_pairs<DAMP, WANT_SSQ, WANT_ACC, NARROW>(lds, ld, K, L, k0, kk, kn, s, ssq, acc_out, stride);
-    kk = integrate_pairs<DAMP, WANT_SSQ, WANT_ACC, WIDE>(lds, ld, K, L, k0, kk, kn, s, ssq, acc_out, stride);
-    if (kk < kn) {  // odd last sample of the chunk: one full-evaluation step
-      const double *v = lds + 2 * kk;
-      const double vprev = s.V;
-      rk4_cold<DAMP>(s, v[0], v[1], v[2], L, K);
-      eval_full(s.ms, s.x, L, K, s.w, s.rx);
-      const double ak = (s.V - vprev) * K.inv_dt;
-      if (WANT_ACC) acc_out[(int64_t)(k0 + kk) * stride] = ak;
-      if (WANT_SSQ) {
-        const double r = ak - ld[kk];
-        ssq += r * r;
-      }
-    }
+    integrate_tiers<DAMP, WANT_SSQ, WANT_ACC, true>(lds, ld, K, L, k0, kn, s, ssq, acc_out, stride);
     return;
   }
+#ifndef RSF_S1_ONLY
+  integrate_tiers<DAMP, WANT_SSQ, WANT_ACC, false>(lds, ld, K, L, k0, kn, s, ssq, acc_out, stride);
+  return;
 #endif
+#endif
+#if defined(RSF_NO_INCREMENTAL) || defined(RSF_S1_ONLY)
   int j = 0;
   for (int kk = 0; kk < kn; ++kk) {
     const double vprev = s.V;
@@ -397,6 +432,7 @@ __device__ __forceinline__ void integrate_chunk(const double *lds, const Consts 
       ssq += r * r;
     }
   }
+#endif
 }
 
 // Full forward solve for one lane.  Every thread of the workgroup must call it (chunk staging has barriers);

@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--rounds", type=int, default=7)
     ap.add_argument("--params", type=int, default=1, choices=[1, 3], help="1: Dc;  3: (Dc, a, b)")
+    ap.add_argument("--substeps", type=int, default=1, help="RK4 steps per output interval")
     ap.add_argument("--precision", default="float64", choices=["float64", "float32"])
     ap.add_argument("variants", nargs="*")
     args = ap.parse_args()
@@ -47,7 +48,7 @@ def main():
     V0 = torch.diag(torch.tensor([20.0 ** 2, 1e-4 ** 2, 1e-4 ** 2][:d], dtype=torch.float64, device="cuda")).repeat(C, 1, 1)
     for name, lib in libs.items():
         e = pkg.Engine(lib=lib, mem="device")
-        e.set_model(model, 1)
+        e.set_model(model, args.substeps)
         e.mcmc_init(q0, data, [0.0, 0.005, 0.005][:d], [1.0e4, 0.02, 0.03][:d], seed=2025, prior_len=3 if d == 1 else 0)
         if d == 3:
             e.set_state(V=V0)
@@ -63,8 +64,8 @@ def main():
             b.record()
             torch.cuda.synchronize()
             times[name].append(a.elapsed_time(b))
-    work = C * ips * args.nsteps
-    print(f"chains={C} nsteps={args.nsteps} iters/launch={ips} rounds={args.rounds} params={d} {args.precision}")
+    work = C * ips * args.nsteps * args.substeps  # RK4 steps
+    print(f"chains={C} nsteps={args.nsteps} substeps={args.substeps} iters/launch={ips} rounds={args.rounds} params={d} {args.precision}")
     for name, t in times.items():
         med, mn = float(np.median(t)), float(np.min(t))
         print(f"  {name:16s} median {med:9.3f} ms  min {mn:9.3f} ms   {work / (med * 1e-3):.4e} steps*chains/s")
