@@ -718,7 +718,7 @@ int rsf_set_model(rsf_ctx *c, const rsf_model *m) {
   if (rc) return rc;
   HIP_TRY(hipMemcpyAsync(c->vl.p, vl.data(), nvl * sizeof(double), hipMemcpyHostToDevice, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));  // vl (host vector) goes out of scope
-  if (c->have_chains && nout != c->nout) free_chains(c);  // observation length changed
+  if (c->have_chains) free_chains(c);  // chain state (SSq, sigma^2, covariance) belongs to the previous model
   c->m = *m;
   c->delta_t = delta_t; c->h = h; c->nout = nout;
   c->kc = (int32_t)kc;

@@ -129,7 +129,8 @@ int rsf_sync(rsf_ctx *ctx);
 
 /* Stores the model attributes and builds the chain-independent loading table
  * V_l(t) = V_ref (1 + exp(-t/20) sin(10 t)) (RateStateModel.py:327-329) at the
- * 2*substeps*(nout-1)+1 RK4 stage times. */
+ * 2*substeps*(nout-1)+1 RK4 stage times.  Discards the chains of an earlier rsf_mcmc_init (their SSq,
+ * sigma^2 and covariance belong to the previous model). */
 int rsf_set_model(rsf_ctx *ctx, const rsf_model *model);
 
 /* Length of the output series: int(floor((t_final-t_start)/delta_t)), RateStateModel.py:358. */

@@ -183,6 +183,7 @@ int rsf_set_model(rsf_ctx *c, const rsf_model *m) {
   if (m->flags & RSF_FLAG_FP32_SOLVE)
     return fail(RSF_ERR_UNSUPPORTED, "rsf_set_model: the CPU restatement is float64 only (the float32 solve is "
                                      "checked against the float64 GPU path within the sweep tolerance)");
+  if (c->have_chains) free_chains(c);  /* chain state belongs to the previous model */
   c->m = *m;
   c->delta_t = (m->t_final - m->t_start) / m->nsteps;                   /* RateStateModel.py:176 */
   c->nout = (int32_t)floor((m->t_final - m->t_start) / c->delta_t);     /* RateStateModel.py:358 */
