@@ -76,7 +76,7 @@ def cpu_baseline(model, data, target_s=12.0):
 
     lib = pkg._abi.bind(ctypes.CDLL(rsf_oracle.lib_path()))
     cores = effective_cpus()
-    chains = 16 * cores
+    chains = 256 * cores
     with pkg.Engine(lib=lib, cpu_threads=cores) as e:
         nout = e.set_model(model, 1)
         e.mcmc_init(np.full((chains, 1), 1000.0), data, [0.0], [1.0e4], seed=2025, prior_len=3)
