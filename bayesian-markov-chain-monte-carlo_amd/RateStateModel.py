@@ -6,7 +6,7 @@ solve runs on the GPU through the C ABI (rsf_forward_batch) as a fixed-step RK4 
 (`substeps` steps per output interval) instead of the reference's SciPy dop853 call.  DESIGN.md
 states the resulting tolerance ladder against the reference trajectory.
 
-Additive surface: `substeps`, `precision`, `evaluate_batch(dc, a=None, b=None)`.
+Additive surface: `substeps`, `precision`, `integrator`, `evaluate_batch(dc, a=None, b=None)`.
 """
 import numpy as np
 
@@ -41,13 +41,14 @@ class RateStateModel:
         self.Dc = None
         self.substeps = 1  # RK4 steps per delta_t (additive knob; 1 = BASELINE's "fixed-step RK4 nsteps")
         self.precision = "float64"  # additive: "float32" integrates the ODE in single precision (tolerance sweeps)
+        self.integrator = "rk4"     # additive: "dop853" = the reference's own adaptive scheme (scipy ode, rtol 1e-6, atol 1e-10)
         self._engine = None
         self._engine_key = None
 
     # ---- engine plumbing ----------------------------------------------------------------
     def _model_key(self):
         return (self.a, self.b, self.mu_ref, self.V_ref, self.k1, self.t_start, self.t_final, self.num_tsteps,
-                self.mu_t_zero, bool(self.RadiationDamping), int(self.substeps), self.precision)
+                self.mu_t_zero, bool(self.RadiationDamping), int(self.substeps), self.precision, self.integrator)
 
     def engine(self):
         """Host-memory Engine bound to the HIP library, re-armed when an attribute changed."""

@@ -19,6 +19,7 @@ OK = 0
 MEM_HOST, MEM_DEVICE = 0, 1
 FLAG_RADIATION_DAMPING = 1
 FLAG_FP32_SOLVE = 2
+FLAG_DOP853 = 4
 ADAPT_NONE, ADAPT_REFERENCE_DICT, ADAPT_AM = 0, 1, 2
 ADAPT_MODES = {"none": ADAPT_NONE, "reference_dict": ADAPT_REFERENCE_DICT, "am": ADAPT_AM}
 MAX_PARAMS = 3

@@ -1,0 +1,167 @@
+// rsf_device_dop853.h — the reference's own integration scheme on the GPU (RSF_FLAG_DOP853).
+//
+// RateStateModel.evaluate drives scipy.integrate.ode('dop853', rtol=1e-6, atol=1e-10) once per output interval
+// (RateStateModel.py:374-389).  This is that algorithm per lane: Hairer's DOP853 step (12 stages, 8th order, 5th/3rd
+// order error estimators), step-size control with safety 0.9 and factors 0.3 .. 6 (beta = 0), at most 500 steps per
+// call, HMAX = interval length, HINIT on the first call and the predicted step size carried from call to call
+// (scipy keeps it in the work array).  After the first interval every call is normally ONE accepted step of
+// length delta_t, so lanes stay convergent.  The RHS is evaluated in full (including the loading velocity at the
+// stage time) — this mode is for fidelity to the reference's numbers (agreement ~1e-12 with its trajectories),
+// the fixed-step RK4 path is the fast one.  Tableau: include/rsf_dop853_tableau.h (generated from SciPy's table).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/rsf_dop853_tableau.h"
+#include "rsf_device.h"
+
+namespace rsf {
+namespace dp {
+
+constexpr double kRtol = 1e-6, kAtol = 1e-10;
+
+struct LaneD {
+  double inv_dc, kprime, inv_a, b;
+};
+
+// RateStateModel.py:318-355 at time t (loading velocity evaluated, not tabulated)
+template <bool DAMP>
+__device__ __forceinline__ void friction(const Consts &K, const LaneD &L, double t, const double y[3], double f[3]) {
+  const double vl = K.V_ref * (1.0 + fm::exp(t * (-1.0 / 20.0)) * ::sin(10.0 * t));
+  const double v = K.V_ref * fm::exp(L.inv_a * (y[0] - K.mu_ref - L.b * fm::log(K.V_ref * y[1] * L.inv_dc)));
+  f[1] = 1.0 - v * y[1] * L.inv_dc;
+  f[0] = L.kprime * (vl - v);
+  const double bt = L.b * fm::rcp(y[1]) * f[1], va = v * L.inv_a;
+  f[2] = va * (f[0] - bt);
+  if (DAMP) {
+    f[0] = f[0] - K.k1 * f[2];
+    f[2] = va * (f[0] - bt);
+  }
+}
+
+template <bool DAMP>
+__device__ __forceinline__ double hinit(const Consts &K, const LaneD &L, double x, const double y[3], const double f0[3],
+                                        double hmax) {
+  double dnf = 0.0, dny = 0.0, y1[3], f1[3], der2 = 0.0;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const double sk = kAtol + kRtol * fabs(y[i]);
+    dnf += (f0[i] / sk) * (f0[i] / sk);
+    dny += (y[i] / sk) * (y[i] / sk);
+  }
+  double h = (dnf <= 1e-10 || dny <= 1e-10) ? 1.0e-6 : sqrt(dny / dnf) * 0.01;
+  h = fmin(h, hmax);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) y1[i] = y[i] + h * f0[i];
+  friction<DAMP>(K, L, x + h, y1, f1);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const double sk = kAtol + kRtol * fabs(y[i]);
+    der2 += ((f1[i] - f0[i]) / sk) * ((f1[i] - f0[i]) / sk);
+  }
+  der2 = sqrt(der2) / h;
+  const double der12 = fmax(fabs(der2), sqrt(dnf));
+  const double h1 = der12 <= 1e-15 ? fmax(1.0e-6, fabs(h) * 1.0e-3) : pow(0.01 / der12, 1.0 / 8.0);
+  return fmin(fmin(100.0 * fabs(h), h1), hmax);
+}
+
+// one dop853 call (forward in time): y from x to xend; hc = carried step size (0 => HINIT).  false on failure.
+template <bool DAMP>
+__device__ __forceinline__ bool call(const Consts &K, const LaneD &L, double &x, double xend, double y[3], double &hc) {
+  constexpr double safe = 0.9, facc1 = 1.0 / 0.3, facc2 = 1.0 / 6.0, uround = 2.3e-16;
+  const double hmax = fabs(xend - x);
+  double k[12][3], ys[3], k5[3];
+  double h = hc;
+  bool last = false, reject = false;
+  friction<DAMP>(K, L, x, y, k[0]);
+  if (h == 0.0) h = hinit<DAMP>(K, L, x, y, k[0], hmax);
+  for (int nstep = 0;; ) {
+    if (nstep > 500) return false;
+    if (0.1 * fabs(h) <= fabs(x) * uround) return false;
+    if (x + 1.01 * h - xend > 0.0) { h = xend - x; last = true; }
+    ++nstep;
+#pragma unroll
+    for (int st = 1; st < 12; ++st) {
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        double s = 0.0;
+#pragma unroll
+        for (int j = 0; j < st; ++j)
+          if (RSF_DP_A[st - 1][j] != 0.0) s += RSF_DP_A[st - 1][j] * k[j][i];
+        ys[i] = y[i] + h * s;
+      }
+      friction<DAMP>(K, L, st == 11 ? x + h : x + RSF_DP_C[st] * h, ys, k[st]);
+    }
+    double err = 0.0, err2 = 0.0;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      double s = 0.0, e3 = 0.0, e5 = 0.0;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const double kj = k[RSF_DP_W_STAGE[j]][i];
+        s += RSF_DP_B[j] * kj;
+        e3 += RSF_DP_E3[j] * kj;
+        e5 += RSF_DP_E5[j] * kj;
+      }
+      k5[i] = y[i] + h * s;
+      const double sk = kAtol + kRtol * fmax(fabs(y[i]), fabs(k5[i]));
+      err2 += (e3 / sk) * (e3 / sk);
+      err += (e5 / sk) * (e5 / sk);
+    }
+    double deno = err + 0.01 * err2;
+    if (deno <= 0.0) deno = 1.0;
+    err = fabs(h) * err * sqrt(1.0 / (3.0 * deno));
+    const double fac11 = pow(err, 1.0 / 8.0);
+    double hnew = h / fmax(facc2, fmin(facc1, fac11 / safe));
+    if (err <= 1.0) {
+      friction<DAMP>(K, L, x + h, k5, k[0]);  // first-same-as-last
+#pragma unroll
+      for (int i = 0; i < 3; ++i) y[i] = k5[i];
+      x = x + h;
+      if (last) { hc = hnew; return true; }
+      if (fabs(hnew) > hmax) hnew = hmax;
+      if (reject) hnew = fmin(fabs(hnew), fabs(h));
+      reject = false;
+    } else {
+      hnew = h / fmin(facc1, fac11 / safe);
+      reject = true;
+      last = false;
+    }
+    h = hnew;
+  }
+}
+
+// Forward solve in the reference's scheme.  Same calling convention as rsf::solve (all threads call it; the
+// observation is read from the LDS chunk staged by stage_chunk).
+template <bool DAMP, bool WANT_SSQ, bool WANT_ACC>
+__device__ __forceinline__ double solve(double *lds, const Consts &K, bool resident, bool active, double dc, double a,
+                                        double b, double *acc_out, int64_t stride) {
+  LaneD L;
+  L.inv_dc = 1.0 / dc; L.kprime = (1e-2 * 10) / dc; L.inv_a = 1.0 / a; L.b = b;
+  const double delta_t = K.h * K.S, inv_dt = K.inv_dt;
+  double y[3] = {K.mu0, dc / K.V_ref, K.V_ref};
+  double x = K.t0, vprev = K.V_ref, hc = 0.0, ssq = 0.0;
+  bool failed = false;
+  if (WANT_SSQ && active) { const double d0 = K.data[0]; ssq = d0 * d0; }
+  if (WANT_ACC && active) acc_out[0] = 0.0;
+  const double *ld = lds + lds_data_offset(K);
+  for (int k0 = 1; k0 < K.nout; k0 += K.kc) {
+    const int kn = min(K.kc, K.nout - k0);
+    if (!resident) stage_chunk(lds, K, k0, kn);
+    if (!active) continue;
+    for (int kk = 0; kk < kn; ++kk) {
+      double ak = 0.0;  // after a failed call the reference's arrays keep their zeros (RateStateModel.py:361-381)
+      if (!failed) {
+        failed = !call<DAMP>(K, L, x, x + delta_t, y, hc);
+        ak = (y[2] - vprev) * inv_dt;
+        vprev = y[2];
+      }
+      if (WANT_ACC) acc_out[(int64_t)(k0 + kk) * stride] = ak;
+      if (WANT_SSQ) { const double r = ak - ld[kk]; ssq = __builtin_fma(r, r, ssq); }
+    }
+  }
+  return ssq;
+}
+
+}  // namespace dp
+}  // namespace rsf

@@ -24,6 +24,7 @@
 
 #include "../../include/rsf_abi.h"
 #include "rsf_device.h"
+#include "rsf_device_dop853.h"
 #include "rsf_device_f32.h"
 
 using rsf::Consts;
@@ -46,13 +47,15 @@ int fail(int code, const char *fmt, ...) {
     if (e_ != hipSuccess) return fail(RSF_ERR_DEVICE, "%s -> %s", #expr, hipGetErrorString(e_)); \
   } while (0)
 
+enum Mode : int { RK4_F64 = 0, RK4_F32 = 1, DOP853 = 2 };  // how the ODE is integrated (rsf_model.flags)
+
 constexpr int kMaxBlock = 256;           // 4 waves: one per SIMD of a CU
 constexpr size_t kLdsBudget = 32 * 1024; // per workgroup; 4 workgroups/CU still fit in 160 KiB
 
 // ---------------------------------------------------------------------------------------------
 // kernels
 // ---------------------------------------------------------------------------------------------
-template <bool DAMP, bool WANT_SSQ, bool WANT_ACC, bool F32>
+template <bool DAMP, bool WANT_SSQ, bool WANT_ACC, int MODE>
 __global__ void __launch_bounds__(kMaxBlock)
 forward_kernel(Consts K, int64_t n, const double *__restrict__ dc, const double *__restrict__ a,
                const double *__restrict__ b, double *__restrict__ ssq_out, double *__restrict__ acc_out) {
@@ -65,13 +68,14 @@ forward_kernel(Consts K, int64_t n, const double *__restrict__ dc, const double 
   double *acc_i = WANT_ACC ? acc_out + i : nullptr;
   const bool resident = K.nchunks == 1;
   double ssq;
-  if constexpr (F32) {
+  if constexpr (MODE == RK4_F32) {
     float *lds32 = reinterpret_cast<float *>(lds);
     if (resident) rsf::f32::stage_chunk32(lds32, K, 1, K.nout - 1);
     ssq = rsf::f32::solve32<DAMP, WANT_SSQ, WANT_ACC>(lds32, K, resident, active, dci, ai, bi, acc_i, n);
   } else {
     if (resident) rsf::stage_chunk(lds, K, 1, K.nout - 1);
-    ssq = rsf::solve<DAMP, WANT_SSQ, WANT_ACC>(lds, K, resident, active, dci, ai, bi, acc_i, n);
+    if constexpr (MODE == DOP853) ssq = rsf::dp::solve<DAMP, WANT_SSQ, WANT_ACC>(lds, K, resident, active, dci, ai, bi, acc_i, n);
+    else ssq = rsf::solve<DAMP, WANT_SSQ, WANT_ACC>(lds, K, resident, active, dci, ai, bi, acc_i, n);
   }
   if (WANT_SSQ && active) ssq_out[i] = ssq;
 }
@@ -154,6 +158,77 @@ __global__ void __launch_bounds__(kMaxBlock) init_kernel(Consts K, InitArgs A) {
   }
 }
 
+// compute_initial_covariance + initial SSq in the reference's DOP853 scheme: the unperturbed and the perturbed
+// trajectories take their dop853 calls interval by interval in one lane (each with its own carried step size).
+template <int D, bool DAMP>
+__global__ void __launch_bounds__(kMaxBlock) init_dp_kernel(Consts K, InitArgs A) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  rsf::select_group(K);
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool active = i < A.C;
+  double p0[3] = {1.0, K.a_def, K.b_def};
+  if (active) {
+    p0[0] = A.q0[i * D];
+    if (D == 3) { p0[1] = A.q0[i * D + 1]; p0[2] = A.q0[i * D + 2]; }
+  }
+  rsf::dp::LaneD L[D + 1];
+  double y[D + 1][3], x[D + 1], hc[D + 1], vprev[D + 1], inv_den[D];
+  bool failed[D + 1];
+#pragma unroll
+  for (int t = 0; t <= D; ++t) {
+    double pq[3] = {p0[0], p0[1], p0[2]};
+    if (t > 0) {
+      pq[t - 1] = pq[t - 1] * (1 + A.fd);
+      inv_den[t - 1] = 1.0 / (pq[t - 1] * A.fd);  // perturbed value in the denominator, MCMC.py:264
+    }
+    L[t].inv_dc = 1.0 / pq[0]; L[t].kprime = (1e-2 * 10) / pq[0]; L[t].inv_a = 1.0 / pq[1]; L[t].b = pq[2];
+    y[t][0] = K.mu0; y[t][1] = pq[0] / K.V_ref; y[t][2] = K.V_ref;
+    x[t] = K.t0; hc[t] = 0.0; vprev[t] = K.V_ref; failed[t] = false;
+  }
+  double xtx[D * D];
+#pragma unroll
+  for (int e = 0; e < D * D; ++e) xtx[e] = 0.0;
+  double ssq = 0.0;
+  if (active) { const double d0 = K.data[0]; ssq = d0 * d0; }
+  const double *ld = lds + rsf::lds_data_offset(K);
+  const double delta_t = K.h * K.S;
+  for (int k0 = 1; k0 < K.nout; k0 += K.kc) {
+    const int kn = min(K.kc, K.nout - k0);
+    rsf::stage_chunk(lds, K, k0, kn);
+    if (!active) continue;
+    for (int kk = 0; kk < kn; ++kk) {
+      double ak[D + 1];
+#pragma unroll
+      for (int t = 0; t <= D; ++t) {
+        ak[t] = 0.0;
+        if (!failed[t]) {
+          failed[t] = !rsf::dp::call<DAMP>(K, L[t], x[t], x[t] + delta_t, y[t], hc[t]);
+          ak[t] = (y[t][2] - vprev[t]) * K.inv_dt;
+          vprev[t] = y[t][2];
+        }
+      }
+      const double r = ak[0] - ld[kk];
+      ssq += r * r;
+      double xs[D];
+#pragma unroll
+      for (int p = 0; p < D; ++p) xs[p] = (ak[p + 1] - ak[0]) * inv_den[p];
+#pragma unroll
+      for (int p = 0; p < D; ++p)
+#pragma unroll
+        for (int r2 = 0; r2 < D; ++r2) xtx[p * D + r2] += xs[p] * xs[r2];
+    }
+  }
+  if (active) {
+    const double std2 = ssq * A.inv_dof;
+    double xi[D * D];
+    rsf::sym_inverse<D>(xtx, xi);
+#pragma unroll
+    for (int e = 0; e < D * D; ++e) A.V[i * D * D + e] = std2 * xi[e];  // MCMC.py:266
+    A.std2[i] = std2;
+    A.ssq[i] = ssq;
+  }
+}
+
 // float32 mode: the sampler compares sums of squares from float32 solves, so the initial SSq (computed by the
 // float64 init kernel together with the float64-only sensitivities) is replaced by its float32 value.
 template <int D, bool DAMP>
@@ -183,7 +258,7 @@ struct McmcArgs {
   uint8_t *ta;
 };
 
-template <int D, bool DAMP, bool REPLAY, bool F32>
+template <int D, bool DAMP, bool REPLAY, int MODE>
 __global__ void __launch_bounds__(kMaxBlock) mcmc_kernel(Consts K, McmcArgs A) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   rsf::select_group(K);
@@ -219,7 +294,7 @@ __global__ void __launch_bounds__(kMaxBlock) mcmc_kernel(Consts K, McmcArgs A) {
 
   float *lds32 = reinterpret_cast<float *>(lds);
   if (resident) {
-    if constexpr (F32) rsf::f32::stage_chunk32(lds32, K, 1, K.nout - 1);
+    if constexpr (MODE == RK4_F32) rsf::f32::stage_chunk32(lds32, K, 1, K.nout - 1);
     else rsf::stage_chunk(lds, K, 1, K.nout - 1);
   }
 
@@ -258,7 +333,8 @@ __global__ void __launch_bounds__(kMaxBlock) mcmc_kernel(Consts K, McmcArgs A) {
     double ssqn = 0.0;
     // (a wave with no in-bounds lane skips the solve when the tables are resident: no barrier inside)
     if (!resident || __any(inb)) {
-      if constexpr (F32) ssqn = rsf::f32::solve32<DAMP, true, false>(lds32, K, resident, inb, qn[0], an, bn, nullptr, 0);
+      if constexpr (MODE == RK4_F32) ssqn = rsf::f32::solve32<DAMP, true, false>(lds32, K, resident, inb, qn[0], an, bn, nullptr, 0);
+      else if constexpr (MODE == DOP853) ssqn = rsf::dp::solve<DAMP, true, false>(lds, K, resident, inb, qn[0], an, bn, nullptr, 0);
       else ssqn = rsf::solve<DAMP, true, false>(lds, K, resident, inb, qn[0], an, bn, nullptr, 0);
     }
     // ---- accept / reject, MCMC.py:327-333 ----
@@ -554,6 +630,7 @@ Consts make_consts(const rsf_ctx *c, const double *data) {
   K.a_def = c->m.a; K.b_def = c->m.b;
   K.h = c->h; K.hh = 0.5 * c->h; K.h6 = c->h / 6.0;
   K.inv_dt = 1.0 / c->delta_t;
+  K.t0 = c->m.t_start;
   K.vl = (const double *)c->vl.p;
   K.data = data;
   K.nout = c->nout; K.S = c->m.substeps; K.kc = c->kc; K.nchunks = c->nchunks;
@@ -563,21 +640,32 @@ Consts make_consts(const rsf_ctx *c, const double *data) {
 
 unsigned grid_for(const rsf_ctx *c, int64_t n) { return (unsigned)((n + c->block - 1) / c->block); }
 
-template <int D, bool DAMP, bool F32>
+int mode_of(const rsf_ctx *c) {
+  return (c->m.flags & RSF_FLAG_DOP853) ? DOP853 : ((c->m.flags & RSF_FLAG_FP32_SOLVE) ? RK4_F32 : RK4_F64);
+}
+
+template <int D, bool DAMP, int MODE>
 int launch_mcmc(rsf_ctx *c, const Consts &K, const McmcArgs &A, bool replay) {
   const dim3 grid(grid_for(c, A.C)), block(c->block);
   if (replay)
-    hipLaunchKernelGGL((mcmc_kernel<D, DAMP, true, F32>), grid, block, c->lds_bytes, c->stream, K, A);
+    hipLaunchKernelGGL((mcmc_kernel<D, DAMP, true, MODE>), grid, block, c->lds_bytes, c->stream, K, A);
   else
-    hipLaunchKernelGGL((mcmc_kernel<D, DAMP, false, F32>), grid, block, c->lds_bytes, c->stream, K, A);
+    hipLaunchKernelGGL((mcmc_kernel<D, DAMP, false, MODE>), grid, block, c->lds_bytes, c->stream, K, A);
   return RSF_OK;
+}
+
+template <int D, bool DAMP>
+int launch_mcmc_m(rsf_ctx *c, const Consts &K, const McmcArgs &A, bool replay) {
+  switch (mode_of(c)) {
+    case RK4_F32: return launch_mcmc<D, DAMP, RK4_F32>(c, K, A, replay);
+    case DOP853: return launch_mcmc<D, DAMP, DOP853>(c, K, A, replay);
+    default: return launch_mcmc<D, DAMP, RK4_F64>(c, K, A, replay);
+  }
 }
 
 template <int D>
 int launch_mcmc_d(rsf_ctx *c, const Consts &K, const McmcArgs &A, bool replay) {
-  const bool damp = c->m.flags & RSF_FLAG_RADIATION_DAMPING, f32 = c->m.flags & RSF_FLAG_FP32_SOLVE;
-  if (f32) return damp ? launch_mcmc<D, true, true>(c, K, A, replay) : launch_mcmc<D, false, true>(c, K, A, replay);
-  return damp ? launch_mcmc<D, true, false>(c, K, A, replay) : launch_mcmc<D, false, false>(c, K, A, replay);
+  return (c->m.flags & RSF_FLAG_RADIATION_DAMPING) ? launch_mcmc_m<D, true>(c, K, A, replay) : launch_mcmc_m<D, false>(c, K, A, replay);
 }
 
 int run_mcmc(rsf_ctx *c, int64_t n_iters, const double *z, const double *u, const double *g, double *tq,
@@ -695,6 +783,8 @@ int rsf_set_model(rsf_ctx *c, const rsf_model *m) {
   if (m->size != sizeof(rsf_model)) return fail(RSF_ERR_INVALID, "rsf_set_model: struct size mismatch");
   if (m->nsteps < 2 || m->substeps < 1 || !(m->t_final > m->t_start))
     return fail(RSF_ERR_INVALID, "rsf_set_model: need nsteps >= 2, substeps >= 1, t_final > t_start");
+  if ((m->flags & RSF_FLAG_DOP853) && (m->flags & RSF_FLAG_FP32_SOLVE))
+    return fail(RSF_ERR_INVALID, "rsf_set_model: the dop853 integrator is float64 only");
   DeviceGuard guard(c->device);
   if (!guard.ok) return fail(RSF_ERR_DEVICE, "rsf_set_model: cannot select device %d", c->device);
   const double delta_t = (m->t_final - m->t_start) / m->nsteps;                  // RateStateModel.py:176
@@ -756,16 +846,17 @@ int rsf_forward_batch(rsf_ctx *c, int64_t n, const double *dc, const double *a, 
   const Consts K = make_consts(c, (const double *)ddata);
   const dim3 grid(grid_for(c, n)), block(c->block);
   const bool damp = c->m.flags & RSF_FLAG_RADIATION_DAMPING;
+#define RSF_LAUNCH_FWD_M(DAMP, SSQ, ACC, MODE)                                                              \
+  hipLaunchKernelGGL((forward_kernel<DAMP, SSQ, ACC, MODE>), grid, block, c->lds_bytes, c->stream, K, n,      \
+                     (const double *)ddc, (const double *)da, (const double *)db, (double *)dssq, (double *)dacc)
 #define RSF_LAUNCH_FWD(DAMP, SSQ, ACC)                                                                      \
   do {                                                                                                      \
-    if (f32)                                                                                                \
-      hipLaunchKernelGGL((forward_kernel<DAMP, SSQ, ACC, true>), grid, block, c->lds_bytes, c->stream, K, n, \
-                         (const double *)ddc, (const double *)da, (const double *)db, (double *)dssq, (double *)dacc); \
-    else                                                                                                    \
-      hipLaunchKernelGGL((forward_kernel<DAMP, SSQ, ACC, false>), grid, block, c->lds_bytes, c->stream, K, n, \
-                         (const double *)ddc, (const double *)da, (const double *)db, (double *)dssq, (double *)dacc); \
+    switch (mode_of(c)) {                                                                                   \
+      case RK4_F32: RSF_LAUNCH_FWD_M(DAMP, SSQ, ACC, RK4_F32); break;                                       \
+      case DOP853: RSF_LAUNCH_FWD_M(DAMP, SSQ, ACC, DOP853); break;                                         \
+      default: RSF_LAUNCH_FWD_M(DAMP, SSQ, ACC, RK4_F64); break;                                            \
+    }                                                                                                       \
   } while (0)
-  const bool f32 = c->m.flags & RSF_FLAG_FP32_SOLVE;
   const int sel = (damp ? 4 : 0) | (ssq_out ? 2 : 0) | (acc_out ? 1 : 0);
   switch (sel) {
     case 0: case 4: break;  // nothing requested
@@ -777,6 +868,7 @@ int rsf_forward_batch(rsf_ctx *c, int64_t n, const double *dc, const double *a, 
     case 7: RSF_LAUNCH_FWD(true, true, true); break;
   }
 #undef RSF_LAUNCH_FWD
+#undef RSF_LAUNCH_FWD_M
   if ((rc = copy_back(c, 4, ssq_out, nb))) return rc;
   if ((rc = copy_back(c, 5, acc_out, nb * (size_t)c->nout))) return rc;
   return finish(c);
@@ -831,7 +923,15 @@ int rsf_mcmc_init(rsf_ctx *c, const rsf_mcmc_config *cfg, const double *q0, cons
   K.group_chains = c->group_chains;
   const dim3 grid(grid_for(c, C)), block(c->block);
   const bool damp = c->m.flags & RSF_FLAG_RADIATION_DAMPING;
-  if (d == 1) {
+  if (c->m.flags & RSF_FLAG_DOP853) {
+    if (d == 1) {
+      if (damp) hipLaunchKernelGGL((init_dp_kernel<1, true>), grid, block, c->lds_bytes, c->stream, K, A);
+      else hipLaunchKernelGGL((init_dp_kernel<1, false>), grid, block, c->lds_bytes, c->stream, K, A);
+    } else {
+      if (damp) hipLaunchKernelGGL((init_dp_kernel<3, true>), grid, block, c->lds_bytes, c->stream, K, A);
+      else hipLaunchKernelGGL((init_dp_kernel<3, false>), grid, block, c->lds_bytes, c->stream, K, A);
+    }
+  } else if (d == 1) {
     if (damp) hipLaunchKernelGGL((init_kernel<1, true>), grid, block, c->lds_bytes, c->stream, K, A);
     else hipLaunchKernelGGL((init_kernel<1, false>), grid, block, c->lds_bytes, c->stream, K, A);
   } else {

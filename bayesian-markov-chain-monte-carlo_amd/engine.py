@@ -24,6 +24,13 @@ def _model_struct(model, substeps):
         raise ValueError(f"precision must be 'float64' or 'float32', not {precision!r}")
     if precision == "float32":
         m.flags |= _abi.FLAG_FP32_SOLVE
+    integrator = getattr(model, "integrator", "rk4")
+    if integrator not in ("rk4", "dop853"):
+        raise ValueError(f"integrator must be 'rk4' or 'dop853', not {integrator!r}")
+    if integrator == "dop853":
+        if precision != "float64":
+            raise ValueError("the dop853 integrator is float64 only")
+        m.flags |= _abi.FLAG_DOP853
     m.nsteps = int(model.num_tsteps)
     m.substeps = int(substeps)
     m.t_start, m.t_final = float(model.t_start), float(model.t_final)

@@ -60,6 +60,9 @@ extern "C" {
 
 /* rsf_model.flags */
 #define RSF_FLAG_RADIATION_DAMPING 1u /* RateStateModel.RadiationDamping, RateStateModel.py:183 */
+#define RSF_FLAG_DOP853 4u            /* integrate exactly like the reference: Hairer's DOP853, rtol 1e-6, atol 1e-10, one
+                                         call per output interval with the step size carried between calls
+                                         (RateStateModel.py:374-389 through scipy.integrate.ode); `substeps` is ignored */
 #define RSF_FLAG_FP32_SOLVE 2u        /* integrate the ODE in float32 (BASELINE config 5 tolerance sweep); all
                                          interface arrays, the SSq accumulator and the sampler logic stay float64 */
 

@@ -27,6 +27,7 @@
  * vectors.
  */
 #include "../include/rsf_abi.h"
+#include "../include/rsf_dop853_tableau.h"
 
 #include <math.h>
 #include <stdio.h>
@@ -220,9 +221,12 @@ static void friction(const rsf_model *m, double t, double dc, double a, double b
 /* One forward solve: fixed-step classical RK4, `substeps` steps per output interval.
  * Stage times are t_start + j*(h/2) with integer j, so that the product's tabulated V_l
  * sees bit-identical arguments.  Returns SSq if data != NULL; writes acc[k*stride] if acc. */
+static double solve_dop853(const rsf_ctx *c, double dc, double a, double b, const double *data, double *acc, int64_t stride);
+
 static double solve(const rsf_ctx *c, double dc, double a, double b, const double *data, double *acc,
                     int64_t stride) {
   const rsf_model *m = &c->m;
+  if (m->flags & RSF_FLAG_DOP853) return solve_dop853(c, dc, a, b, data, acc, stride);
   const int S = m->substeps;
   const double h = c->h, hh = 0.5 * c->h;
   double y[3] = {m->mu_t_zero, dc / m->V_ref, m->V_ref}; /* RateStateModel.py:367-377 */
@@ -250,6 +254,132 @@ static double solve(const rsf_ctx *c, double dc, double a, double b, const doubl
     vprev = y[2];
     if (acc) acc[k * stride] = ak;
     if (data) ssq += (ak - data[k]) * (ak - data[k]);
+  }
+  return ssq;
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* The reference's own integrator: Hairer's DOP853 as scipy.integrate.ode('dop853') drives it     */
+/* (RateStateModel.py:374-389): rtol 1e-6, atol 1e-10, safety 0.9, step factors 0.3 .. 6, beta 0, */
+/* at most 500 steps per call, one call per output interval, HMAX = interval length, and the     */
+/* predicted step size carried from one call to the next through the work array (first call:     */
+/* HINIT).  Restated from the published algorithm (Hairer, Norsett, Wanner: Solving ODEs I,      */
+/* II.10 / dop853.f); the tableau comes from include/rsf_dop853_tableau.h.                        */
+/* ------------------------------------------------------------------------------------ */
+#define DP_RTOL 1e-6
+#define DP_ATOL 1e-10
+
+typedef struct {
+  double h;      /* WORK(7): step size proposed by the previous call (0 => HINIT) */
+  int failed;    /* r.successful() turned false: the reference stops integrating (trailing zeros) */
+} dp_carry;
+
+static double dp_hinit(const rsf_ctx *c, double dc, double a, double b, double x, const double y[3], double posneg,
+                       const double f0[3], double hmax) {
+  double dnf = 0.0, dny = 0.0, y1[3], f1[3], der2 = 0.0, h, h1, der12;
+  for (int i = 0; i < 3; ++i) {
+    double sk = DP_ATOL + DP_RTOL * fabs(y[i]);
+    dnf += (f0[i] / sk) * (f0[i] / sk);
+    dny += (y[i] / sk) * (y[i] / sk);
+  }
+  h = (dnf <= 1e-10 || dny <= 1e-10) ? 1.0e-6 : sqrt(dny / dnf) * 0.01;
+  h = fmin(h, hmax);
+  h = copysign(h, posneg);
+  for (int i = 0; i < 3; ++i) y1[i] = y[i] + h * f0[i];
+  friction(&c->m, x + h, dc, a, b, y1, f1);
+  for (int i = 0; i < 3; ++i) {
+    double sk = DP_ATOL + DP_RTOL * fabs(y[i]);
+    der2 += ((f1[i] - f0[i]) / sk) * ((f1[i] - f0[i]) / sk);
+  }
+  der2 = sqrt(der2) / h;
+  der12 = fmax(fabs(der2), sqrt(dnf));
+  h1 = der12 <= 1e-15 ? fmax(1.0e-6, fabs(h) * 1.0e-3) : pow(0.01 / der12, 1.0 / 8.0);
+  h = fmin(fmin(100 * fabs(h), h1), hmax);
+  return copysign(h, posneg);
+}
+
+/* one call of dop853: integrate y from *x to xend; returns 1 on success (IDID = 1) */
+static int dp_call(const rsf_ctx *c, double dc, double a, double b, double *x, double xend, double y[3], dp_carry *cw) {
+  const double safe = 0.9, facc1 = 1.0 / 0.3, facc2 = 1.0 / 6.0, expo1 = 1.0 / 8.0, uround = 2.3e-16;
+  const double posneg = copysign(1.0, xend - *x), hmax = fabs(xend - *x);
+  double k[12][3], ys[3], h = cw->h, hnew;
+  int last = 0, reject = 0, nstep = 0;
+  friction(&c->m, *x, dc, a, b, y, k[0]);
+  if (h == 0.0) h = dp_hinit(c, dc, a, b, *x, y, posneg, k[0], hmax);
+  for (;;) {
+    if (nstep > 500) return 0;                                     /* NMAX */
+    if (0.1 * fabs(h) <= fabs(*x) * uround) return 0;              /* step size too small */
+    if ((*x + 1.01 * h - xend) * posneg > 0.0) { h = xend - *x; last = 1; }
+    ++nstep;
+    for (int st = 1; st < 12; ++st) {                              /* the twelve stages */
+      for (int i = 0; i < 3; ++i) {
+        double s = 0.0;
+        for (int j = 0; j < st; ++j) s += RSF_DP_A[st - 1][j] * k[j][i];
+        ys[i] = y[i] + h * s;
+      }
+      friction(&c->m, st == 11 ? *x + h : *x + RSF_DP_C[st] * h, dc, a, b, ys, k[st]);
+    }
+    double k4[3], k5[3], err = 0.0, err2 = 0.0, deno;
+    for (int i = 0; i < 3; ++i) {
+      double s = 0.0;
+      for (int j = 0; j < 8; ++j) s += RSF_DP_B[j] * k[RSF_DP_W_STAGE[j]][i];
+      k4[i] = s;
+      k5[i] = y[i] + h * s;
+    }
+    for (int i = 0; i < 3; ++i) {                                  /* error estimation */
+      double sk = DP_ATOL + DP_RTOL * fmax(fabs(y[i]), fabs(k5[i])), e3 = 0.0, e5 = 0.0;
+      for (int j = 0; j < 8; ++j) {
+        e3 += RSF_DP_E3[j] * k[RSF_DP_W_STAGE[j]][i];
+        e5 += RSF_DP_E5[j] * k[RSF_DP_W_STAGE[j]][i];
+      }
+      err2 += (e3 / sk) * (e3 / sk);
+      err += (e5 / sk) * (e5 / sk);
+    }
+    deno = err + 0.01 * err2;
+    if (deno <= 0.0) deno = 1.0;
+    err = fabs(h) * err * sqrt(1.0 / (3 * deno));
+    double fac11 = pow(err, expo1), fac = fmax(facc2, fmin(facc1, fac11 / safe));   /* beta = 0 */
+    hnew = h / fac;
+    if (err <= 1.0) {                                              /* step accepted */
+      friction(&c->m, *x + h, dc, a, b, k5, k[0]);                 /* first-same-as-last */
+      for (int i = 0; i < 3; ++i) y[i] = k5[i];
+      *x = *x + h;
+      if (last) { cw->h = hnew; return 1; }
+      if (fabs(hnew) > hmax) hnew = posneg * hmax;
+      if (reject) hnew = posneg * fmin(fabs(hnew), fabs(h));
+      reject = 0;
+    } else {                                                       /* step rejected */
+      hnew = h / fmin(facc1, fac11 / safe);
+      reject = 1;
+      last = 0;
+    }
+    h = hnew;
+  }
+}
+
+static double solve_dop853(const rsf_ctx *c, double dc, double a, double b, const double *data, double *acc, int64_t stride) {
+  const rsf_model *m = &c->m;
+  double y[3] = {m->mu_t_zero, dc / m->V_ref, m->V_ref};           /* RateStateModel.py:377 */
+  double x = m->t_start, vprev = m->V_ref, ssq = 0.0;
+  dp_carry cw = {0.0, 0};
+  if (acc) acc[0] = 0.0;
+  if (data) ssq = (0.0 - data[0]) * (0.0 - data[0]);
+  for (int32_t kk = 1; kk < c->nout; ++kk) {                       /* RateStateModel.py:380-389 */
+    double ak = 0.0;                                               /* zero-initialised arrays keep 0 after a failure */
+    if (!cw.failed) {
+      if (dp_call(c, dc, a, b, &x, x + c->delta_t, y, &cw)) {
+        ak = (y[2] - vprev) / c->delta_t;
+        vprev = y[2];
+      } else {
+        /* the failing call still returns its partial state and the loop body runs once more before
+         * r.successful() is tested: record that sample, then stop */
+        ak = (y[2] - vprev) / c->delta_t;
+        vprev = y[2];
+        cw.failed = 1;
+      }
+    }
+    if (acc) acc[kk * stride] = ak;
+    if (data) ssq += (ak - data[kk]) * (ak - data[kk]);
   }
   return ssq;
 }

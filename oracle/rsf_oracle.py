@@ -40,6 +40,7 @@ class ModelSpec:
         self.RadiationDamping = True
         self.substeps = substeps
         self.precision = "float64"
+        self.integrator = "rk4"
 
     @property
     def nout(self):

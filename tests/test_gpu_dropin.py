@@ -34,6 +34,18 @@ def test_config1_chain_matches_the_reference_run(pkg, golden):
     assert mc.std2.shape == (501,)
 
 
+def test_config1_chain_is_identical_with_the_reference_integrator(pkg, golden):
+    """integrator = "dop853": seeded MCMC.sample(False) gives the reference's 1000-proposal chain, all 501 kept samples."""
+    g = golden.npz("config1")
+    model = pkg.RateStateModel(number_time_steps=500)
+    model.integrator = "dop853"
+    np.random.seed(2025)
+    mc = pkg.MCMC(model, g["data"], 1000.0, ["Uniform", 0.0, 10000.0], 1000.0, nsamples=1000, lstm_model=None, verbose=False)
+    q = mc.sample(False)
+    np.testing.assert_allclose(q, g["qparams_kept"], rtol=1e-9)
+    np.testing.assert_allclose(mc.std2, g["std2_kept"], rtol=1e-7)
+
+
 def test_batched_posterior_agrees_with_reference_posterior(pkg, golden):
     """Tier 3: pooled GPU posterior (Philox path, RK4 S = 1) vs the reference's long chain."""
     g, meta = golden.npz("config1"), golden.json("config1")

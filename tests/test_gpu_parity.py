@@ -188,6 +188,67 @@ def test_out_of_bounds_proposals_skip_the_solve(gpu_engine, cpu_engine, oracle_m
     assert (tg[0] > 980.0).all() and (tg[0] < 1020.0).all()
 
 
+def _dp(oracle_mod, n, damping=True):
+    m = _models(oracle_mod, n, 1, damping)
+    m.integrator = "dop853"
+    return m
+
+
+def test_dop853_mode_matches_oracle_and_reference(gpu_engine, cpu_engine, oracle_mod, golden):
+    """RSF_FLAG_DOP853: the reference's own adaptive scheme on the GPU — against the CPU restatement (Tier 1) and
+    directly against the reference's golden trajectories, SSq grid and initial covariance (no RK4 ladder needed)."""
+    g, meta = golden.npz("forward"), golden.json("forward")
+    for case in meta["cases"]:
+        m = _dp(oracle_mod, case["nsteps"], case["damping"])
+        m.a, m.b = case["a"], case["b"]
+        gpu_engine.set_model(m, 1)
+        _, acc = gpu_engine.forward([case["dc"]])
+        ref = g[case["tag"]]
+        tol = 1e-9 if case["dc"] >= 10 else 1e-6  # Dc = 1 is stiff: 9 000 RHS calls, step decisions near the tolerance
+        assert np.abs(acc[:, 0] - ref).max() <= tol * np.abs(ref).max(), case["tag"]
+    m = _dp(oracle_mod, 500)
+    for e in (gpu_engine, cpu_engine):
+        e.set_model(m, 1)
+    rng = np.random.default_rng(21)
+    C = 150
+    dc = rng.uniform(80.0, 9000.0, C)
+    a = rng.uniform(0.008, 0.016, C)
+    b = a + rng.uniform(-0.004, 0.008, C)
+    data = synthetic_data(cpu_engine)
+    sg, ag = gpu_engine.forward(dc, a=a, b=b, data=data, want_ssq=True)
+    sc, ac = cpu_engine.forward(dc, a=a, b=b, data=data, want_ssq=True)
+    assert _traj_err(ag, ac) < RTOL
+    np.testing.assert_allclose(sg, sc, rtol=RTOL)
+    gs = golden.npz("ssq")
+    ssq, _ = gpu_engine.forward(gs["qgrid"], data=gs["data"], want_ssq=True, want_acc=False)
+    np.testing.assert_allclose(ssq, gs["ssq"], rtol=1e-9)  # == MCMC.SSqcalc of the reference
+    for name, c in golden.json("init")["cases"].items():
+        gpu_engine.mcmc_init([[c["qstart"]]], gs["data"], [0.0], [1e4], prior_len=c["prior_len"])
+        _, _, std2, V = gpu_engine.get_state()
+        np.testing.assert_allclose(std2[0], c["std2_0"], rtol=1e-9, err_msg=name)
+        np.testing.assert_allclose(V[0, 0, 0], c["vstart"], rtol=1e-5, err_msg=name)
+
+
+@pytest.mark.parametrize("tag", ["list", "dict", "tightbox"])
+def test_dop853_mode_replays_the_reference_chain(gpu_engine, golden, oracle_mod, tag):
+    """Same variates + same integrator: the GPU kernel walks the reference's chain, every iteration."""
+    g, meta = golden.npz("replay_" + tag), golden.json("replay_" + tag)
+    is_list = isinstance(meta["prior"], list)
+    lo, hi = (meta["prior"][1], meta["prior"][2]) if is_list else (meta["prior"]["1"], meta["prior"]["2"])
+    gpu_engine.set_model(_dp(oracle_mod, meta["nsteps"]), 1)
+    gpu_engine.mcmc_init([[meta["qstart"]]], g["data"], [lo], [hi], prior_len=3 if is_list else 2,
+                         adapt_mode="none" if is_list else "reference_dict", adapt_interval=meta["adapt_interval"])
+    _, ssq, std2, V = gpu_engine.get_state()
+    np.testing.assert_allclose([ssq[0], std2[0]], [meta["ssq0"], meta["std2_0"]], rtol=1e-9)
+    gpu_engine.set_state(V=[[[meta["vstart"]]]])
+    n = len(g["z"])
+    u = np.where(np.isnan(g["u"]), 1.0, g["u"])
+    tq, ts, ta = gpu_engine.mcmc_replay(g["z"].reshape(n, 1, 1), u.reshape(n, 1), g["g"].reshape(n, 1))
+    np.testing.assert_allclose(tq[:, 0, 0], np.append(g["q_cur"][1:], g["qparams_kept"][0, -1]), rtol=1e-10)
+    np.testing.assert_allclose(ts[:, 0], g["std2_after"], rtol=1e-8)
+    assert gpu_engine.stats()["evaluated"] == int(g["inb"].sum())
+
+
 def test_edge_cases_and_call_order(pkg, cpu_engine, oracle_mod):
     m = _models(oracle_mod, 500)
     cpu_engine.set_model(m, 1)

@@ -216,3 +216,63 @@ def test_pool_summary_and_kde_match_numpy_and_scipy(cpu_engine):
         np.testing.assert_allclose(cpu_engine.pool_kde(trace, grid, param=p), gaussian_kde(x).pdf(grid), rtol=1e-10, atol=1e-300)
     with pytest.raises(Exception):
         cpu_engine.pool_kde(np.full(10, 3.0), np.linspace(0, 1, 5))  # zero variance: singular, like scipy
+
+
+# ---- the reference's own integrator (RSF_FLAG_DOP853): no convergence argument needed -------------------------
+def _dp_model(oracle_mod, case_or_n, **kw):
+    n = case_or_n if isinstance(case_or_n, int) else case_or_n["nsteps"]
+    m = oracle_mod.ModelSpec(n)
+    m.integrator = "dop853"
+    if not isinstance(case_or_n, int):
+        m.RadiationDamping, m.a, m.b = case_or_n["damping"], case_or_n["a"], case_or_n["b"]
+    return m
+
+
+def test_dop853_restatement_reproduces_reference_trajectories(cpu_engine, oracle_mod, golden):
+    """Hairer's DOP853 driven the way scipy.integrate.ode drives it (step size carried between the per-interval
+    calls, HINIT on the first) gives the reference's evaluate()[1] to rounding for EVERY golden case, the stiff
+    Dc = 1 one included."""
+    g, meta = golden.npz("forward"), golden.json("forward")
+    exact = 0
+    for case in meta["cases"]:
+        cpu_engine.set_model(_dp_model(oracle_mod, case), 1)
+        _, acc = cpu_engine.forward([case["dc"]])
+        ref = g[case["tag"]]
+        err = np.abs(acc[:, 0] - ref).max() / np.abs(ref).max()
+        assert err < 1e-10, (case["tag"], err)
+        exact += err == 0.0
+    assert exact >= 8  # most cases are bit-identical
+
+
+def test_dop853_ssq_and_initial_covariance_match_reference(cpu_engine, oracle_mod, golden):
+    g, cases = golden.npz("ssq"), golden.json("init")["cases"]
+    cpu_engine.set_model(_dp_model(oracle_mod, 500), 1)
+    ssq, _ = cpu_engine.forward(g["qgrid"], data=g["data"], want_ssq=True, want_acc=False)
+    np.testing.assert_allclose(ssq, g["ssq"], rtol=1e-11)
+    for name, c in cases.items():
+        cpu_engine.mcmc_init([[c["qstart"]]], g["data"], [0.0], [1e4], prior_len=c["prior_len"])
+        _, _, std2, V = cpu_engine.get_state()
+        np.testing.assert_allclose(std2[0], c["std2_0"], rtol=1e-11, err_msg=name)
+        np.testing.assert_allclose(V[0, 0, 0], c["vstart"], rtol=1e-6, err_msg=name)  # 1e-6 forward difference of ~1e-12 noise
+
+
+@pytest.mark.parametrize("tag", ["list", "dict", "tightbox"])
+def test_dop853_chain_equals_reference_chain(cpu_engine, oracle_mod, golden, tag):
+    """Same variates + same integrator = the reference's chain, every iteration (no recorded SSq injected)."""
+    g, meta = golden.npz("replay_" + tag), golden.json("replay_" + tag)
+    is_list = isinstance(meta["prior"], list)
+    lo, hi = (meta["prior"][1], meta["prior"][2]) if is_list else (meta["prior"]["1"], meta["prior"]["2"])
+    cpu_engine.set_model(_dp_model(oracle_mod, meta["nsteps"]), 1)
+    cpu_engine.mcmc_init([[meta["qstart"]]], g["data"], [lo], [hi], prior_len=3 if is_list else 2,
+                         adapt_mode="none" if is_list else "reference_dict", adapt_interval=meta["adapt_interval"])
+    _, ssq, std2, V = cpu_engine.get_state()
+    np.testing.assert_allclose([ssq[0], std2[0]], [meta["ssq0"], meta["std2_0"]], rtol=1e-11)
+    np.testing.assert_allclose(V[0, 0, 0], meta["vstart"], rtol=1e-6)
+    cpu_engine.set_state(V=[[[meta["vstart"]]]])
+    n = len(g["z"])
+    u = np.where(np.isnan(g["u"]), 1.0, g["u"])
+    tq, ts, ta = cpu_engine.mcmc_replay(g["z"].reshape(n, 1, 1), u.reshape(n, 1), g["g"].reshape(n, 1))
+    np.testing.assert_allclose(tq[:, 0, 0], np.append(g["q_cur"][1:], g["qparams_kept"][0, -1]), rtol=1e-12)
+    np.testing.assert_allclose(ts[:, 0], g["std2_after"], rtol=1e-10)
+    np.testing.assert_allclose(np.where(g["inb"] == 1, g["ssq_new"], 0.0)[ta[:, 0] == 1],
+                               g["ssq_after"][ta[:, 0] == 1], rtol=1e-10)
