@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=7)
     ap.add_argument("--params", type=int, default=1, choices=[1, 3], help="1: Dc;  3: (Dc, a, b)")
     ap.add_argument("--substeps", type=int, default=1, help="RK4 steps per output interval")
+    ap.add_argument("--integrator", default="rk4", choices=["rk4", "dop853"])
     ap.add_argument("--precision", default="float64", choices=["float64", "float32"])
     ap.add_argument("variants", nargs="*")
     args = ap.parse_args()
@@ -41,6 +42,7 @@ def main():
         libs[name] = pkg._abi.bind(ctypes.CDLL(os.path.abspath(path)))
     model, data = synthetic_problem(args.nsteps)
     model.precision = args.precision
+    model.integrator = args.integrator
     C, ips, d = args.chains, args.iters, args.params
     engines, traces = {}, (torch.empty((ips, C, d), dtype=torch.float64, device="cuda"),
                            torch.empty((ips, C), dtype=torch.float64, device="cuda"), None)
