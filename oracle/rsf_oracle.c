@@ -319,11 +319,10 @@ static int dp_call(const rsf_ctx *c, double dc, double a, double b, double *x, d
       }
       friction(&c->m, st == 11 ? *x + h : *x + RSF_DP_C[st] * h, dc, a, b, ys, k[st]);
     }
-    double k4[3], k5[3], err = 0.0, err2 = 0.0, deno;
+    double k5[3], err = 0.0, err2 = 0.0, deno;
     for (int i = 0; i < 3; ++i) {
       double s = 0.0;
       for (int j = 0; j < 8; ++j) s += RSF_DP_B[j] * k[RSF_DP_W_STAGE[j]][i];
-      k4[i] = s;
       k5[i] = y[i] + h * s;
     }
     for (int i = 0; i < 3; ++i) {                                  /* error estimation */
