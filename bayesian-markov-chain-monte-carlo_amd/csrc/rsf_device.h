@@ -25,7 +25,7 @@ struct Consts {
   double a_def, b_def;            // model.a / model.b where no per-lane value is given
   double h, hh, h6;               // RK4 step, h/2, h/6
   double inv_dt;                  // 1 / delta_t
-  double t0;                      // t_start
+  double t0, dt;                  // t_start, delta_t
   const double *vl;               // V_l at stage times t_start + j*h/2, j = 0 .. 2*S*(nout-1)
   const double *data;             // observation [nout] (of this workgroup's chain group) or nullptr
   int64_t group_chains;           // chains per observation group (0: one series for all)

@@ -24,10 +24,14 @@ struct LaneD {
   double inv_dc, kprime, inv_a, b;
 };
 
-// RateStateModel.py:318-355 at time t (loading velocity evaluated, not tabulated)
+// loading velocity V_l(t), RateStateModel.py:327-329
+__device__ __forceinline__ double loading(const Consts &K, double t) {
+  return K.V_ref * (1.0 + fm::exp(t * (-1.0 / 20.0)) * ::sin(10.0 * t));
+}
+
+// RateStateModel.py:318-355 given the loading velocity vl at the evaluation time
 template <bool DAMP>
-__device__ __forceinline__ void friction(const Consts &K, const LaneD &L, double t, const double y[3], double f[3]) {
-  const double vl = K.V_ref * (1.0 + fm::exp(t * (-1.0 / 20.0)) * ::sin(10.0 * t));
+__device__ __forceinline__ void friction(const Consts &K, const LaneD &L, double vl, const double y[3], double f[3]) {
   const double v = K.V_ref * fm::exp(L.inv_a * (y[0] - K.mu_ref - L.b * fm::log(K.V_ref * y[1] * L.inv_dc)));
   f[1] = 1.0 - v * y[1] * L.inv_dc;
   f[0] = L.kprime * (vl - v);
@@ -53,7 +57,7 @@ __device__ __forceinline__ double hinit(const Consts &K, const LaneD &L, double 
   h = fmin(h, hmax);
 #pragma unroll
   for (int i = 0; i < 3; ++i) y1[i] = y[i] + h * f0[i];
-  friction<DAMP>(K, L, x + h, y1, f1);
+  friction<DAMP>(K, L, loading(K, x + h), y1, f1);
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
     const double sk = kAtol + kRtol * fabs(y[i]);
@@ -66,19 +70,25 @@ __device__ __forceinline__ double hinit(const Consts &K, const LaneD &L, double 
 }
 
 // one dop853 call (forward in time): y from x to xend; hc = carried step size (0 => HINIT).  false on failure.
+// `tab` (LDS, 12 values) holds V_l at the stage times of the STANDARD step of this interval — the first step
+// clipped to h = xend - x, which is what every call after the first interval takes; x and xend are the
+// accumulated grid times shared by all lanes, so the host can tabulate them bit-exactly (rsf_set_model).
+// Any other step (HINIT's first interval, steps after a rejection) evaluates V_l(t) directly.
 template <bool DAMP>
-__device__ __forceinline__ bool call(const Consts &K, const LaneD &L, double &x, double xend, double y[3], double &hc) {
+__device__ __forceinline__ bool call(const Consts &K, const LaneD &L, const double *tab, double &x, double xend, double y[3],
+                                     double &hc) {
   constexpr double safe = 0.9, facc1 = 1.0 / 0.3, facc2 = 1.0 / 6.0, uround = 2.3e-16;
   const double hmax = fabs(xend - x);
   double k[12][3], ys[3], k5[3];
   double h = hc;
   bool last = false, reject = false;
-  friction<DAMP>(K, L, x, y, k[0]);
+  friction<DAMP>(K, L, tab[0], y, k[0]);  // V_l(x): x is the interval's start time for every lane
   if (h == 0.0) h = hinit<DAMP>(K, L, x, y, k[0], hmax);
   for (int nstep = 0;; ) {
     if (nstep > 500) return false;
     if (0.1 * fabs(h) <= fabs(x) * uround) return false;
     if (x + 1.01 * h - xend > 0.0) { h = xend - x; last = true; }
+    const bool standard = last && nstep == 0;  // the tabulated step
     ++nstep;
 #pragma unroll
     for (int st = 1; st < 12; ++st) {
@@ -90,7 +100,8 @@ __device__ __forceinline__ bool call(const Consts &K, const LaneD &L, double &x,
           if (RSF_DP_A[st - 1][j] != 0.0) s += RSF_DP_A[st - 1][j] * k[j][i];
         ys[i] = y[i] + h * s;
       }
-      friction<DAMP>(K, L, st == 11 ? x + h : x + RSF_DP_C[st] * h, ys, k[st]);
+      const double vl = standard ? tab[st] : loading(K, st == 11 ? x + h : x + RSF_DP_C[st] * h);
+      friction<DAMP>(K, L, vl, ys, k[st]);
     }
     double err = 0.0, err2 = 0.0;
 #pragma unroll
@@ -114,7 +125,7 @@ __device__ __forceinline__ bool call(const Consts &K, const LaneD &L, double &x,
     const double fac11 = pow(err, 1.0 / 8.0);
     double hnew = h / fmax(facc2, fmin(facc1, fac11 / safe));
     if (err <= 1.0) {
-      friction<DAMP>(K, L, x + h, k5, k[0]);  // first-same-as-last
+      friction<DAMP>(K, L, standard ? tab[11] : loading(K, x + h), k5, k[0]);  // first-same-as-last, at x + h
 #pragma unroll
       for (int i = 0; i < 3; ++i) y[i] = k5[i];
       x = x + h;
@@ -131,28 +142,42 @@ __device__ __forceinline__ bool call(const Consts &K, const LaneD &L, double &x,
   }
 }
 
+// LDS chunk of the DOP853 mode: [ 12 loading values per interval : 12*kc ][ data : kc ]
+constexpr int kTab = 12;
+__device__ __forceinline__ int lds_data_offset_dp(const Consts &K) { return kTab * K.kc; }
+
+__device__ __forceinline__ void stage_chunk_dp(double *lds, const Consts &K, int k0, int kn) {
+  __syncthreads();
+  for (int i = threadIdx.x; i < kTab * kn; i += blockDim.x) lds[i] = K.vl[(int64_t)kTab * (k0 - 1) + i];
+  if (K.data) {
+    double *ld = lds + lds_data_offset_dp(K);
+    for (int i = threadIdx.x; i < kn; i += blockDim.x) ld[i] = K.data[k0 + i];
+  }
+  __syncthreads();
+}
+
 // Forward solve in the reference's scheme.  Same calling convention as rsf::solve (all threads call it; the
-// observation is read from the LDS chunk staged by stage_chunk).
+// loading table and the observation are read from the LDS chunk staged by stage_chunk_dp).
 template <bool DAMP, bool WANT_SSQ, bool WANT_ACC>
 __device__ __forceinline__ double solve(double *lds, const Consts &K, bool resident, bool active, double dc, double a,
                                         double b, double *acc_out, int64_t stride) {
   LaneD L;
   L.inv_dc = 1.0 / dc; L.kprime = (1e-2 * 10) / dc; L.inv_a = 1.0 / a; L.b = b;
-  const double delta_t = K.h * K.S, inv_dt = K.inv_dt;
+  const double delta_t = K.dt, inv_dt = K.inv_dt;
   double y[3] = {K.mu0, dc / K.V_ref, K.V_ref};
   double x = K.t0, vprev = K.V_ref, hc = 0.0, ssq = 0.0;
   bool failed = false;
   if (WANT_SSQ && active) { const double d0 = K.data[0]; ssq = d0 * d0; }
   if (WANT_ACC && active) acc_out[0] = 0.0;
-  const double *ld = lds + lds_data_offset(K);
+  const double *ld = lds + lds_data_offset_dp(K);
   for (int k0 = 1; k0 < K.nout; k0 += K.kc) {
     const int kn = min(K.kc, K.nout - k0);
-    if (!resident) stage_chunk(lds, K, k0, kn);
+    if (!resident) stage_chunk_dp(lds, K, k0, kn);
     if (!active) continue;
     for (int kk = 0; kk < kn; ++kk) {
       double ak = 0.0;  // after a failed call the reference's arrays keep their zeros (RateStateModel.py:361-381)
       if (!failed) {
-        failed = !call<DAMP>(K, L, x, x + delta_t, y, hc);
+        failed = !call<DAMP>(K, L, lds + kTab * kk, x, x + delta_t, y, hc);
         ak = (y[2] - vprev) * inv_dt;
         vprev = y[2];
       }

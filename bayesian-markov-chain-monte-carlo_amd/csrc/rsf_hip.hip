@@ -73,9 +73,13 @@ forward_kernel(Consts K, int64_t n, const double *__restrict__ dc, const double 
     if (resident) rsf::f32::stage_chunk32(lds32, K, 1, K.nout - 1);
     ssq = rsf::f32::solve32<DAMP, WANT_SSQ, WANT_ACC>(lds32, K, resident, active, dci, ai, bi, acc_i, n);
   } else {
-    if (resident) rsf::stage_chunk(lds, K, 1, K.nout - 1);
-    if constexpr (MODE == DOP853) ssq = rsf::dp::solve<DAMP, WANT_SSQ, WANT_ACC>(lds, K, resident, active, dci, ai, bi, acc_i, n);
-    else ssq = rsf::solve<DAMP, WANT_SSQ, WANT_ACC>(lds, K, resident, active, dci, ai, bi, acc_i, n);
+    if constexpr (MODE == DOP853) {
+      if (resident) rsf::dp::stage_chunk_dp(lds, K, 1, K.nout - 1);
+      ssq = rsf::dp::solve<DAMP, WANT_SSQ, WANT_ACC>(lds, K, resident, active, dci, ai, bi, acc_i, n);
+    } else {
+      if (resident) rsf::stage_chunk(lds, K, 1, K.nout - 1);
+      ssq = rsf::solve<DAMP, WANT_SSQ, WANT_ACC>(lds, K, resident, active, dci, ai, bi, acc_i, n);
+    }
   }
   if (WANT_SSQ && active) ssq_out[i] = ssq;
 }
@@ -190,11 +194,11 @@ __global__ void __launch_bounds__(kMaxBlock) init_dp_kernel(Consts K, InitArgs A
   for (int e = 0; e < D * D; ++e) xtx[e] = 0.0;
   double ssq = 0.0;
   if (active) { const double d0 = K.data[0]; ssq = d0 * d0; }
-  const double *ld = lds + rsf::lds_data_offset(K);
-  const double delta_t = K.h * K.S;
+  const double *ld = lds + rsf::dp::lds_data_offset_dp(K);
+  const double delta_t = K.dt;
   for (int k0 = 1; k0 < K.nout; k0 += K.kc) {
     const int kn = min(K.kc, K.nout - k0);
-    rsf::stage_chunk(lds, K, k0, kn);
+    rsf::dp::stage_chunk_dp(lds, K, k0, kn);
     if (!active) continue;
     for (int kk = 0; kk < kn; ++kk) {
       double ak[D + 1];
@@ -202,7 +206,7 @@ __global__ void __launch_bounds__(kMaxBlock) init_dp_kernel(Consts K, InitArgs A
       for (int t = 0; t <= D; ++t) {
         ak[t] = 0.0;
         if (!failed[t]) {
-          failed[t] = !rsf::dp::call<DAMP>(K, L[t], x[t], x[t] + delta_t, y[t], hc[t]);
+          failed[t] = !rsf::dp::call<DAMP>(K, L[t], lds + rsf::dp::kTab * kk, x[t], x[t] + delta_t, y[t], hc[t]);
           ak[t] = (y[t][2] - vprev[t]) * K.inv_dt;
           vprev[t] = y[t][2];
         }
@@ -295,6 +299,7 @@ __global__ void __launch_bounds__(kMaxBlock) mcmc_kernel(Consts K, McmcArgs A) {
   float *lds32 = reinterpret_cast<float *>(lds);
   if (resident) {
     if constexpr (MODE == RK4_F32) rsf::f32::stage_chunk32(lds32, K, 1, K.nout - 1);
+    else if constexpr (MODE == DOP853) rsf::dp::stage_chunk_dp(lds, K, 1, K.nout - 1);
     else rsf::stage_chunk(lds, K, 1, K.nout - 1);
   }
 
@@ -631,6 +636,7 @@ Consts make_consts(const rsf_ctx *c, const double *data) {
   K.h = c->h; K.hh = 0.5 * c->h; K.h6 = c->h / 6.0;
   K.inv_dt = 1.0 / c->delta_t;
   K.t0 = c->m.t_start;
+  K.dt = c->delta_t;
   K.vl = (const double *)c->vl.p;
   K.data = data;
   K.nout = c->nout; K.S = c->m.substeps; K.kc = c->kc; K.nchunks = c->nchunks;
@@ -792,18 +798,39 @@ int rsf_set_model(rsf_ctx *c, const rsf_model *m) {
   if (nout < 2) return fail(RSF_ERR_INVALID, "rsf_set_model: fewer than 2 output samples");
   const int S = m->substeps;
   const double h = delta_t / S, hh = 0.5 * h;
-  // LDS chunking: kc output intervals need (2*S*kc + 1) loading values + kc observations
+  const bool dop = m->flags & RSF_FLAG_DOP853;
   const size_t words = kLdsBudget / sizeof(double) - 2 * rsf::kLdsPad;
-  int64_t kc = ((int64_t)words - 1) / (2 * (int64_t)S + 1);
-  if (kc < 1) return fail(RSF_ERR_UNSUPPORTED, "rsf_set_model: substeps=%d does not fit the LDS staging budget", S);
-  if (kc > nout - 1) kc = nout - 1;
-  // chain-independent loading velocity at every RK4 stage time, RateStateModel.py:327-329
-  const size_t nvl = 2 * (size_t)S * (size_t)(nout - 1) + 1;
-  std::vector<double> vl(nvl);
-  for (size_t j = 0; j < nvl; ++j) {
-    const double t = m->t_start + (double)j * hh;
-    vl[j] = m->V_ref * (1 + std::exp(-t / 20) * std::sin(10 * t));
+  int64_t kc;
+  std::vector<double> vl;
+  if (dop) {
+    // DOP853 mode: per output interval the 12 loading values of the standard step (first step clipped to the
+    // interval).  x is accumulated like scipy's r.t (x <- x + h with h = fl(fl(x + dt) - x)), so the stage times
+    // are bit-identical to the ones the kernel — and the reference — use.
+    kc = (int64_t)words / (rsf::dp::kTab + 1);
+    if (kc > nout - 1) kc = nout - 1;
+    vl.resize((size_t)rsf::dp::kTab * (size_t)(nout - 1));
+    double x = m->t_start;
+    for (int32_t k = 0; k < nout - 1; ++k) {
+      const double xend = x + delta_t, hk = xend - x;
+      for (int st = 0; st < rsf::dp::kTab; ++st) {
+        const double t = st == 0 ? x : (st == 11 ? x + hk : x + RSF_DP_C[st] * hk);
+        vl[(size_t)rsf::dp::kTab * k + st] = m->V_ref * (1 + std::exp(-t / 20) * std::sin(10 * t));
+      }
+      x = x + hk;
+    }
+  } else {
+    // LDS chunking: kc output intervals need (2*S*kc + 1) loading values + kc observations
+    kc = ((int64_t)words - 1) / (2 * (int64_t)S + 1);
+    if (kc < 1) return fail(RSF_ERR_UNSUPPORTED, "rsf_set_model: substeps=%d does not fit the LDS staging budget", S);
+    if (kc > nout - 1) kc = nout - 1;
+    // chain-independent loading velocity at every RK4 stage time, RateStateModel.py:327-329
+    vl.resize(2 * (size_t)S * (size_t)(nout - 1) + 1);
+    for (size_t j = 0; j < vl.size(); ++j) {
+      const double t = m->t_start + (double)j * hh;
+      vl[j] = m->V_ref * (1 + std::exp(-t / 20) * std::sin(10 * t));
+    }
   }
+  const size_t nvl = vl.size();
   int rc = ensure(c->vl, nvl * sizeof(double));
   if (rc) return rc;
   HIP_TRY(hipMemcpyAsync(c->vl.p, vl.data(), nvl * sizeof(double), hipMemcpyHostToDevice, c->stream));
@@ -813,7 +840,7 @@ int rsf_set_model(rsf_ctx *c, const rsf_model *m) {
   c->delta_t = delta_t; c->h = h; c->nout = nout;
   c->kc = (int32_t)kc;
   c->nchunks = (int32_t)((nout - 1 + kc - 1) / kc);
-  c->lds_bytes = (size_t)(2 * S * kc + 1 + kc + 2 * rsf::kLdsPad) * sizeof(double);
+  c->lds_bytes = (size_t)((dop ? rsf::dp::kTab * kc : 2 * S * kc + 1) + kc + 2 * rsf::kLdsPad) * sizeof(double);
   c->have_model = true;
   return RSF_OK;
 }
