@@ -574,6 +574,10 @@ struct rsf_ctx {
   int64_t iters_done = 0;
   // staging for RSF_MEM_HOST callers
   DevBuf stage[8];
+  // drain pipeline of rsf_mcmc_run for RSF_MEM_HOST callers: the trace of launch k is copied out on its own stream
+  // while launch k+1 computes
+  hipStream_t copy_stream = nullptr;
+  hipEvent_t ev_done[2] = {nullptr, nullptr};
   DevBuf pool;  // workspace of the posterior post-processing kernels
 };
 
@@ -674,6 +678,62 @@ int launch_mcmc_d(rsf_ctx *c, const Consts &K, const McmcArgs &A, bool replay) {
   return (c->m.flags & RSF_FLAG_RADIATION_DAMPING) ? launch_mcmc_m<D, true>(c, K, A, replay) : launch_mcmc_m<D, false>(c, K, A, replay);
 }
 
+// RSF_MEM_HOST callers with a long run: launches of `per` iterations write their trace rows into one of two device
+// staging sets; while launch k+1 computes, the rows of launch k go to the caller's arrays on a second stream.  The
+// chain is the same as with one launch (the kernel continues from iter_base; tests: continuation == single launch).
+// trace bytes per launch (cfg1: ~30 iterations, ~5 ms of compute); RSF_DRAIN_BYTES overrides it (tests use a tiny value)
+size_t drain_bytes() {
+  const char *e = std::getenv("RSF_DRAIN_BYTES");
+  const long long v = e ? std::atoll(e) : 0;
+  return v > 0 ? (size_t)v : (size_t)32 << 20;
+}
+
+int run_mcmc_drained(rsf_ctx *c, const Consts &K, McmcArgs A, int64_t per, double *tq, double *ts, uint8_t *ta) {
+  const int d = c->mc.n_params;
+  const size_t C = (size_t)A.C;
+  const int64_t n_iters = A.n_iters;
+  if (!c->copy_stream) {
+    HIP_TRY(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+    for (auto &e : c->ev_done) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  }
+  const int slot_q[2] = {3, 0}, slot_s[2] = {4, 1}, slot_a[2] = {5, 2};
+  int rc;
+  for (int b = 0; b < 2; ++b) {
+    if (tq && (rc = ensure(c->stage[slot_q[b]], (size_t)per * C * d * sizeof(double)))) return rc;
+    if (ts && (rc = ensure(c->stage[slot_s[b]], (size_t)per * C * sizeof(double)))) return rc;
+    if (ta && (rc = ensure(c->stage[slot_a[b]], (size_t)per * C))) return rc;
+  }
+  auto drain = [&](int b, int64_t first, int64_t n) -> int {
+    const size_t r0 = (size_t)first * C, rn = (size_t)n * C;
+    HIP_TRY(hipStreamWaitEvent(c->copy_stream, c->ev_done[b], 0));
+    if (tq) HIP_TRY(hipMemcpyAsync(tq + r0 * d, c->stage[slot_q[b]].p, rn * d * sizeof(double), hipMemcpyDeviceToHost, c->copy_stream));
+    if (ts) HIP_TRY(hipMemcpyAsync(ts + r0, c->stage[slot_s[b]].p, rn * sizeof(double), hipMemcpyDeviceToHost, c->copy_stream));
+    if (ta) HIP_TRY(hipMemcpyAsync(ta + r0, c->stage[slot_a[b]].p, rn, hipMemcpyDeviceToHost, c->copy_stream));
+    HIP_TRY(hipStreamSynchronize(c->copy_stream));  // the staging set is free again, the rows are in the caller's arrays
+    return RSF_OK;
+  };
+  const int64_t base = A.iter_base;
+  int64_t done = 0, prev_first = 0, prev_n = 0;
+  int b = 0;
+  while (done < n_iters) {
+    const int64_t n = std::min(per, n_iters - done);
+    A.n_iters = n; A.iter_base = base + done;
+    A.tq = tq ? (double *)c->stage[slot_q[b]].p : nullptr;
+    A.ts = ts ? (double *)c->stage[slot_s[b]].p : nullptr;
+    A.ta = ta ? (uint8_t *)c->stage[slot_a[b]].p : nullptr;
+    rc = d == 1 ? launch_mcmc_d<1>(c, K, A, false) : launch_mcmc_d<3>(c, K, A, false);
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(c->ev_done[b], c->stream));
+    if (prev_n && (rc = drain(b ^ 1, prev_first, prev_n))) return rc;
+    prev_first = done; prev_n = n;
+    done += n;
+    b ^= 1;
+  }
+  if ((rc = drain(b ^ 1, prev_first, prev_n))) return rc;
+  c->iters_done += n_iters;
+  return finish(c);
+}
+
 int run_mcmc(rsf_ctx *c, int64_t n_iters, const double *z, const double *u, const double *g, double *tq,
              double *ts, uint8_t *ta, bool replay) {
   if (!c || n_iters < 0) return fail(RSF_ERR_INVALID, "rsf_mcmc_run: bad argument");
@@ -698,13 +758,18 @@ int run_mcmc(rsf_ctx *c, int64_t n_iters, const double *z, const double *u, cons
   if ((rc = stage_in(c, 0, z, rows * d * sizeof(double), &dz))) return rc;
   if ((rc = stage_in(c, 1, u, rows * sizeof(double), &du))) return rc;
   if ((rc = stage_in(c, 2, g, rows * sizeof(double), &dg))) return rc;
+  A.z = (const double *)dz; A.u = (const double *)du; A.g = (const double *)dg;
+  Consts K = make_consts(c, (const double *)c->data.p);
+  K.group_chains = c->group_chains;
+  if (host_mem(c) && !replay) {
+    const size_t row_bytes = (size_t)C * ((tq ? d * sizeof(double) : 0) + (ts ? sizeof(double) : 0) + (ta ? 1 : 0));
+    const int64_t per = row_bytes ? std::max<int64_t>(1, (int64_t)(drain_bytes() / row_bytes)) : n_iters;
+    if (per < n_iters) return run_mcmc_drained(c, K, A, per, tq, ts, ta);
+  }
   if ((rc = stage_out(c, 3, tq, rows * d * sizeof(double), &dtq))) return rc;
   if ((rc = stage_out(c, 4, ts, rows * sizeof(double), &dts))) return rc;
   if ((rc = stage_out(c, 5, ta, rows, &dta))) return rc;
-  A.z = (const double *)dz; A.u = (const double *)du; A.g = (const double *)dg;
   A.tq = (double *)dtq; A.ts = (double *)dts; A.ta = (uint8_t *)dta;
-  Consts K = make_consts(c, (const double *)c->data.p);
-  K.group_chains = c->group_chains;
   rc = d == 1 ? launch_mcmc_d<1>(c, K, A, replay) : launch_mcmc_d<3>(c, K, A, replay);
   if (rc) return rc;
   if ((rc = copy_back(c, 3, tq, rows * d * sizeof(double)))) return rc;
@@ -772,6 +837,8 @@ int rsf_destroy(rsf_ctx *c) {
     release(c->vl);
     for (auto &s : c->stage) release(s);
     release(c->pool);
+    for (auto &e : c->ev_done) if (e) (void)hipEventDestroy(e);
+    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
   }
   delete c;
   return RSF_OK;

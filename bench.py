@@ -109,7 +109,7 @@ def main():
     ap.add_argument("--workload", default="cfg1", choices=sorted(WORKLOADS))
     ap.add_argument("--chains", type=int, default=0, help="chains per GPU (default: the workload's)")
     ap.add_argument("--nsteps", type=int, default=0)
-    ap.add_argument("--iters-per-step", type=int, default=10, help="proposals per chain per launch")
+    ap.add_argument("--iters-per-step", type=int, default=100, help="proposals per chain per launch (SURVEY §8d: 100)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend for N > 1 (nccl = RCCL; gloo only to rehearse the N > 1 path on one GPU)")
@@ -188,7 +188,9 @@ def main():
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc):
             with open(pmc) as f:
-                traffic = json.load(f).get(args.workload)
+                t = json.load(f)
+            if t.get(args.workload + "_iters_per_step") == ips and not (args.chains or args.nsteps):
+                traffic = t.get(args.workload)   # PMC bytes per launch, measured for this launch shape
         out = {
             "metric": "ode_steps_x_chains_per_sec", "value": value, "unit": "ODE-steps*chains/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3,

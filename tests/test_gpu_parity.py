@@ -175,6 +175,34 @@ def test_mcmc_continuation_equals_single_launch(gpu_engine, oracle_mod):
         np.testing.assert_array_equal(np.concatenate([p[k] for p in parts]), one[k])
 
 
+def test_host_caller_drain_pipeline_equals_single_launch(pkg, oracle_mod, monkeypatch):
+    """RSF_MEM_HOST runs longer than the drain budget are cut into launches whose trace rows are copied out on a
+    second stream while the next launch computes; the rows must be those of the one-launch run, also when only some
+    of the trace arrays are requested."""
+    m = _models(oracle_mod, 500)
+    q0 = np.full((200, 1), 900.0)
+
+    def run(want):
+        with pkg.Engine(mem="host") as e:
+            e.set_model(m, 1)
+            data = synthetic_data(e)
+            e.mcmc_init(q0, data, [0.0], [1e4], seed=5, prior_len=2, adapt_mode="reference_dict", adapt_interval=5)
+            out = e.mcmc_run(23, traces=want)
+            return out, e.get_state(), e.stats()
+
+    one, st1, s1 = run(True)
+    monkeypatch.setenv("RSF_DRAIN_BYTES", str(200 * 17 * 3 + 5))  # 3 iterations per launch, last launch ragged
+    cut, st2, s2 = run(True)
+    for k in range(3):
+        np.testing.assert_array_equal(cut[k], one[k])
+    for a, b in zip(st1, st2):
+        np.testing.assert_array_equal(a, b)
+    assert s1 == s2 and s2["iters_done"] == 23
+    only_q, _, _ = run(("q",))
+    np.testing.assert_array_equal(only_q[0], one[0])
+    assert only_q[1] is None and only_q[2] is None
+
+
 def test_out_of_bounds_proposals_skip_the_solve(gpu_engine, cpu_engine, oracle_mod):
     m = _models(oracle_mod, 500)
     for e in (gpu_engine, cpu_engine):

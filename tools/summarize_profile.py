@@ -57,12 +57,25 @@ def main():
         summary["valu_insts_per_wave"] = pmc["SQ_INSTS_VALU"] / pmc["SQ_WAVES"]
     if "SQ_ACTIVE_INST_VALU" in pmc and "SQ_BUSY_CYCLES" in pmc:
         summary["note_units"] = "SQ_* cycle counters are in quad-cycles summed over SEs/XCDs (MI355X_MICROARCH.md)"
+    # the bench line printed under the kernel-trace pass: kept beside the summaries; its proposals per launch say
+    # which launch shape the per-launch counters belong to
+    ips = None
+    log = os.path.join(src, "trace.log")
+    if os.path.exists(log):
+        lines = [l for l in open(log) if l.startswith('{"metric"')]
+        if lines:
+            bench = json.loads(lines[-1])
+            ips = bench["config"].get("proposals_per_chain_per_step")
+            summary["bench_kernel_ms_hip_events"] = bench["roofline"].get("kernel_ms")
+            json.dump(bench, open(os.path.join(dst, f"{tag}_{build}_bench.json"), "w"))
+    summary["proposals_per_chain_per_launch"] = ips
     json.dump(summary, open(os.path.join(dst, f"{tag}_{build}_pmc.json"), "w"), indent=1)
     tfile = os.path.join(os.path.dirname(dst.rstrip("/")), "pmc_traffic.json")
     traffic = json.load(open(tfile)) if os.path.exists(tfile) else {}
     if "hbm_bytes_per_launch" in summary:
         traffic[tag] = summary["hbm_bytes_per_launch"]["total_corrected"]
         traffic[tag + "_source"] = f"{dst}/{tag}_{build}_pmc.json"
+        traffic[tag + "_iters_per_step"] = ips
         json.dump(traffic, open(tfile, "w"), indent=1)
     print(json.dumps(summary, indent=1))
 
