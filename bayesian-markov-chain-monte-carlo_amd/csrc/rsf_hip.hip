@@ -13,6 +13,8 @@
 //
 // There is no host fallback in this file: every entry point either runs on the GPU or fails.
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>  // types and prototypes only: the library is bound with dlopen (see struct Rccl)
+#include <dlfcn.h>
 
 #include <cmath>
 #include <cstdarg>
@@ -578,6 +580,9 @@ struct rsf_ctx {
   // while launch k+1 computes
   hipStream_t copy_stream = nullptr;
   hipEvent_t ev_done[2] = {nullptr, nullptr};
+  // posterior-pool communicator (one process per GPU)
+  int32_t world = 0, rank = 0;  // world 0: rsf_comm_init not called
+  ncclComm_t comm = nullptr;
   DevBuf pool;  // workspace of the posterior post-processing kernels
 };
 
@@ -779,6 +784,54 @@ int run_mcmc(rsf_ctx *c, int64_t n_iters, const double *z, const double *u, cons
   return finish(c);
 }
 
+// RCCL, bound at run time: a process that already holds a copy (PyTorch links its own) must not get a second one,
+// and a caller that never pools across GPUs needs none at all.
+struct Rccl {
+  void *h = nullptr;
+  decltype(&ncclGetUniqueId) get_unique_id = nullptr;
+  decltype(&ncclCommInitRank) comm_init_rank = nullptr;
+  decltype(&ncclCommDestroy) comm_destroy = nullptr;
+  decltype(&ncclAllGather) all_gather = nullptr;
+  decltype(&ncclAllReduce) all_reduce = nullptr;
+  decltype(&ncclGetErrorString) error_string = nullptr;
+};
+
+const Rccl *rccl() {
+  static Rccl r;
+  static bool tried = false;
+  if (tried) return r.h ? &r : nullptr;
+  tried = true;
+  const char *env = std::getenv("RSF_RCCL_LIB");
+  const char *names[] = {"librccl.so", "librccl.so.1"};
+  if (env && *env) r.h = dlopen(env, RTLD_NOW | RTLD_GLOBAL);
+  for (const char *n : names) if (!r.h) r.h = dlopen(n, RTLD_NOW | RTLD_NOLOAD);  // the copy already in the process
+  if (!r.h) {  // a copy PyTorch loaded by path is found through one of its symbols
+    Dl_info info;
+    void *sym = dlsym(RTLD_DEFAULT, "ncclGetUniqueId");
+    if (sym && dladdr(sym, &info) && info.dli_fname) r.h = dlopen(info.dli_fname, RTLD_NOW | RTLD_NOLOAD);
+  }
+  for (const char *n : names) if (!r.h) r.h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+  if (!r.h) r.h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+  if (!r.h) return nullptr;
+  r.get_unique_id = (decltype(r.get_unique_id))dlsym(r.h, "ncclGetUniqueId");
+  r.comm_init_rank = (decltype(r.comm_init_rank))dlsym(r.h, "ncclCommInitRank");
+  r.comm_destroy = (decltype(r.comm_destroy))dlsym(r.h, "ncclCommDestroy");
+  r.all_gather = (decltype(r.all_gather))dlsym(r.h, "ncclAllGather");
+  r.all_reduce = (decltype(r.all_reduce))dlsym(r.h, "ncclAllReduce");
+  r.error_string = (decltype(r.error_string))dlsym(r.h, "ncclGetErrorString");
+  if (!r.get_unique_id || !r.comm_init_rank || !r.comm_destroy || !r.all_gather || !r.all_reduce || !r.error_string) {
+    r.h = nullptr;
+    return nullptr;
+  }
+  return &r;
+}
+
+#define RCCL_TRY(R, expr)                                                                          \
+  do {                                                                                             \
+    ncclResult_t e_ = (expr);                                                                      \
+    if (e_ != ncclSuccess) return fail(RSF_ERR_DEVICE, "%s -> %s", #expr, (R)->error_string(e_));  \
+  } while (0)
+
 void free_chains(rsf_ctx *c) {
   release(c->data); release(c->q); release(c->ssq); release(c->std2); release(c->V);
   release(c->wref); release(c->wsum); release(c->wsq); release(c->wn); release(c->stats);
@@ -837,6 +890,7 @@ int rsf_destroy(rsf_ctx *c) {
     release(c->vl);
     for (auto &s : c->stage) release(s);
     release(c->pool);
+    if (c->comm) { const Rccl *R = rccl(); if (R) (void)R->comm_destroy(c->comm); }
     for (auto &e : c->ev_done) if (e) (void)hipEventDestroy(e);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
   }
@@ -1160,6 +1214,86 @@ int rsf_pool_kde(rsf_ctx *c, int64_t n, const double *x, int64_t stride, int32_t
   hipLaunchKernelGGL(pool_kde_reduce_kernel, dim3((m + kMaxBlock - 1) / kMaxBlock), dim3(kMaxBlock), 0, c->stream, blocks, (int)m,
                      (const double *)ws.p, 1.0 / ((double)n * std::sqrt(2.0 * 3.14159265358979323846 * cov)), (double *)dd);
   if ((rc = copy_back(c, 2, density, (size_t)m * sizeof(double)))) return rc;
+  return finish(c);
+}
+
+int rsf_comm_unique_id(uint8_t id[RSF_COMM_ID_BYTES]) {
+  if (!id) return fail(RSF_ERR_INVALID, "rsf_comm_unique_id: NULL argument");
+  static_assert(sizeof(ncclUniqueId) == RSF_COMM_ID_BYTES, "RCCL unique id size");
+  const Rccl *R = rccl();
+  if (!R) return fail(RSF_ERR_UNSUPPORTED, "rsf_comm_unique_id: RCCL (librccl.so) could not be loaded: %s", dlerror());
+  ncclUniqueId u;
+  RCCL_TRY(R, R->get_unique_id(&u));
+  std::memcpy(id, u.internal, RSF_COMM_ID_BYTES);
+  return RSF_OK;
+}
+
+int rsf_comm_init(rsf_ctx *c, int32_t world, int32_t rank, const uint8_t id[RSF_COMM_ID_BYTES]) {
+  if (!c || world < 1 || rank < 0 || rank >= world) return fail(RSF_ERR_INVALID, "rsf_comm_init: bad argument");
+  if (c->world) return fail(RSF_ERR_STATE, "rsf_comm_init: this ctx already has a communicator (rsf_comm_destroy first)");
+  if (world > 1 && !id) return fail(RSF_ERR_INVALID, "rsf_comm_init: world > 1 needs the id from rsf_comm_unique_id on rank 0");
+  if (id) {  // (world = 1 with an id makes a real one-rank communicator: the single-GPU test of the RCCL binding)
+    const Rccl *R = rccl();
+    if (!R) return fail(RSF_ERR_UNSUPPORTED, "rsf_comm_init: RCCL (librccl.so) could not be loaded");
+    DeviceGuard guard(c->device);
+    if (!guard.ok) return fail(RSF_ERR_DEVICE, "rsf_comm_init: cannot select device %d", c->device);
+    ncclUniqueId u;
+    std::memcpy(u.internal, id, RSF_COMM_ID_BYTES);
+    RCCL_TRY(R, R->comm_init_rank(&c->comm, world, u, rank));
+  }
+  c->world = world;
+  c->rank = rank;
+  return RSF_OK;
+}
+
+int rsf_comm_destroy(rsf_ctx *c) {
+  if (!c) return fail(RSF_ERR_INVALID, "rsf_comm_destroy: NULL ctx");
+  if (c->comm) {
+    DeviceGuard guard(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    const Rccl *R = rccl();
+    if (R) RCCL_TRY(R, R->comm_destroy(c->comm));
+    c->comm = nullptr;
+  }
+  c->world = 0;
+  c->rank = 0;
+  return RSF_OK;
+}
+
+int rsf_pool_allgather(rsf_ctx *c, const double *send, int64_t count, double *recv) {
+  if (!c || !send || !recv || count < 1) return fail(RSF_ERR_INVALID, "rsf_pool_allgather: bad argument");
+  if (!c->world) return fail(RSF_ERR_STATE, "rsf_pool_allgather: call rsf_comm_init first");
+  DeviceGuard guard(c->device);
+  if (!guard.ok) return fail(RSF_ERR_DEVICE, "rsf_pool_allgather: cannot select device %d", c->device);
+  const size_t bytes = (size_t)count * sizeof(double);
+  const void *ds;
+  void *dr;
+  int rc;
+  if ((rc = stage_in(c, 0, send, bytes, &ds))) return rc;
+  if ((rc = stage_out(c, 1, recv, bytes * (size_t)c->world, &dr))) return rc;
+  if (!c->comm) {
+    if (dr != ds) HIP_TRY(hipMemcpyAsync(dr, ds, bytes, hipMemcpyDeviceToDevice, c->stream));
+  } else {
+    const Rccl *R = rccl();
+    RCCL_TRY(R, R->all_gather(ds, dr, (size_t)count, ncclFloat64, c->comm, c->stream));
+  }
+  if ((rc = copy_back(c, 1, recv, bytes * (size_t)c->world))) return rc;
+  return finish(c);
+}
+
+int rsf_pool_allreduce_sum(rsf_ctx *c, double *buf, int64_t count) {
+  if (!c || !buf || count < 1) return fail(RSF_ERR_INVALID, "rsf_pool_allreduce_sum: bad argument");
+  if (!c->world) return fail(RSF_ERR_STATE, "rsf_pool_allreduce_sum: call rsf_comm_init first");
+  if (!c->comm) return RSF_OK;
+  DeviceGuard guard(c->device);
+  if (!guard.ok) return fail(RSF_ERR_DEVICE, "rsf_pool_allreduce_sum: cannot select device %d", c->device);
+  const size_t bytes = (size_t)count * sizeof(double);
+  const void *ds;
+  int rc;
+  if ((rc = stage_in(c, 0, buf, bytes, &ds))) return rc;
+  const Rccl *R = rccl();
+  RCCL_TRY(R, R->all_reduce(ds, (void *)ds, (size_t)count, ncclFloat64, ncclSum, c->comm, c->stream));
+  if (host_mem(c)) HIP_TRY(hipMemcpyAsync(buf, ds, bytes, hipMemcpyDeviceToHost, c->stream));
   return finish(c);
 }
 

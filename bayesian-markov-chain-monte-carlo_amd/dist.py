@@ -52,6 +52,27 @@ def allgather_pool(local, group=None):
     return out.view((world,) + tuple(local.shape))
 
 
+def comm_init_from_process_group(engine, group=None, device=None):
+    """Create `engine`'s own RCCL communicator (C ABI: rsf_comm_unique_id / rsf_comm_init) for the ranks of a
+    torch.distributed group.  torch.distributed is only the side channel that carries rank 0's 128-byte id; the
+    collectives themselves (Engine.pool_allgather / pool_allreduce_sum) then run inside the library on the ctx
+    stream, so a caller without PyTorch can do the same with any other way of moving 128 bytes."""
+    import torch
+    import torch.distributed as dist
+
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    if world == 1:
+        engine.comm_init(1, 0, engine.comm_unique_id())  # a real one-rank communicator, same code path as world > 1
+        return
+    if device is None:
+        device = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
+    uid = torch.zeros(128, dtype=torch.uint8, device=device)
+    if rank == 0:
+        uid = torch.tensor(list(engine.comm_unique_id()), dtype=torch.uint8, device=device)
+    dist.broadcast(uid, src=0, group=group)
+    engine.comm_init(world, rank, bytes(uid.cpu().tolist()))
+
+
 def allreduce_summary(local, group=None, device=None):
     """Summary path: combine per-rank `Engine.pool_summary` dicts {n, mean, var, min, max} into the
     global moments with three tiny all-reduces (SUM of n / sum / centred sum of squares, MIN, MAX) instead of

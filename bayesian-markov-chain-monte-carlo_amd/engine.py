@@ -66,6 +66,7 @@ class Engine:
         _abi.check(lib, lib.rsf_create(ctypes.byref(cfg), ctypes.byref(self._ctx)))
         self.nout = None
         self.n_chains = self.n_params = None
+        self.world = self.rank = 0  # set by comm_init
 
     # -- lifetime -------------------------------------------------------------------------
     def close(self):
@@ -235,6 +236,41 @@ class Engine:
         _abi.check(self.lib, self.lib.rsf_pool_kde(self._ctx, n, self._ptr(x) + 8 * p, d, m, self._ptr(grid), float(bw_factor),
                                                    self._ptr(dens)))
         return dens
+
+    # -- multi-GPU posterior pool through the C ABI (RCCL bound inside the library) -----
+    def comm_unique_id(self):
+        """Rank 0: the 128-byte id every rank passes to comm_init (send it over any channel)."""
+        buf = (ctypes.c_uint8 * 128)()
+        _abi.check(self.lib, self.lib.rsf_comm_unique_id(buf))
+        return bytes(buf)
+
+    def comm_init(self, world, rank, unique_id=None):
+        """Collective: create this ctx's communicator (world = 1 needs no id)."""
+        buf = (ctypes.c_uint8 * 128)(*unique_id) if unique_id is not None else None
+        _abi.check(self.lib, self.lib.rsf_comm_init(self._ctx, int(world), int(rank), buf))
+        self.world, self.rank = int(world), int(rank)
+
+    def comm_destroy(self):
+        _abi.check(self.lib, self.lib.rsf_comm_destroy(self._ctx))
+        self.world = 0
+
+    def pool_allgather(self, local):
+        """local: array/tensor of any shape in this engine's memory space → (world,) + shape on every rank."""
+        if not self.world:
+            raise _abi.RsfError(-3, "pool_allgather: call comm_init first")
+        x = self._in(local)
+        out = self._empty((self.world,) + tuple(x.shape))
+        n = int(np.prod(x.shape))
+        _abi.check(self.lib, self.lib.rsf_pool_allgather(self._ctx, self._ptr(x), n, self._ptr(out)))
+        return out
+
+    def pool_allreduce_sum(self, buf):
+        """In-place element-wise sum over ranks of a float64 array/tensor in this engine's memory space."""
+        if not self.world:
+            raise _abi.RsfError(-3, "pool_allreduce_sum: call comm_init first")
+        x = self._in(buf)
+        _abi.check(self.lib, self.lib.rsf_pool_allreduce_sum(self._ctx, self._ptr(x), int(np.prod(x.shape))))
+        return x
 
     # -- RNG helpers (tests) --------------------------------------------------------------
     def philox(self, ctr, key):

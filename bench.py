@@ -101,6 +101,38 @@ def cpu_baseline(model, data, target_s=12.0):
                        f"oracle/librsf_oracle.so with OpenMP over chains, {wall:.1f} s")
 
 
+def abi_pool_allgather(eng, local, expected_pool, rdist, timeout_s=90.0):
+    """The same posterior-pool exchange through the C ABI (rsf_comm_init + rsf_pool_allgather: the library's own
+    RCCL communicator on the engine's stream), checked against the torch.distributed pool.  Outside the timed
+    region, and under a watchdog so that it can never cost the result line."""
+    import threading
+
+    import torch
+
+    res = {"status": "timeout"}
+    dev = torch.cuda.current_device()
+
+    def work():
+        try:
+            torch.cuda.set_device(dev)
+            rdist.comm_init_from_process_group(eng)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            out = eng.pool_allgather(local)
+            eng.sync()
+            ms = (time.perf_counter() - t0) * 1e3
+            same = bool(torch.equal(rdist.pool_to_chain_major(out), expected_pool))
+            eng.comm_destroy()
+            res.update(status="ok", ms=ms, equals_torch_pool=same)
+        except Exception as exc:  # reported, never fatal: the torch.distributed pool above is the one that counts
+            res.update(status="error", error=str(exc)[:200])
+
+    th = threading.Thread(target=work, daemon=True)
+    th.start()
+    th.join(timeout_s)
+    return dict(res)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -174,8 +206,9 @@ def main():
         torch.cuda.synchronize()
         allgather_ms = (time.perf_counter() - g0) * 1e3
         assert pool.shape == (ips, world * C, 1)
+        abi_pool = abi_pool_allgather(eng, traces[0], pool, rdist) if args.backend == "nccl" else None
     else:
-        allgather_ms = None
+        allgather_ms = abi_pool = None
 
     if rank == 0:
         proposals = world * C * ips * args.steps
@@ -209,9 +242,13 @@ def main():
         }
         if allgather_ms is not None:
             out["pool_allgather_ms"] = allgather_ms
+        if abi_pool is not None:
+            out["pool_allgather_c_abi"] = abi_pool
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(model, data)
         print(json.dumps(out), flush=True)
+    if abi_pool is not None and abi_pool.get("status") == "timeout":
+        os._exit(0)  # a rank stuck inside a collective cannot be torn down cleanly; the result line is out
     eng.close()
     if world > 1:
         dist.destroy_process_group()

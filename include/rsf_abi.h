@@ -200,6 +200,27 @@ int rsf_pool_summary(rsf_ctx *ctx, int64_t n, const double *x, int64_t stride, d
 int rsf_pool_kde(rsf_ctx *ctx, int64_t n, const double *x, int64_t stride, int32_t m, const double *grid,
                  double bw_factor, double *density);
 
+/* ---- multi-GPU posterior pool: one process per GPU, RCCL over xGMI -----------------
+ * The reference runs its chains one after another in one process (RSF.py:1040-1046); here each rank
+ * samples its own block of global chain ids with no exchange, and the kept rows are pooled ONCE.
+ *   rank 0:      rsf_comm_unique_id(id), hands the 128 bytes to the other ranks by any channel
+ *                (torch.distributed broadcast, MPI, a file ...);
+ *   every rank:  rsf_comm_init(ctx, world, rank, id)   — collective, creates the RCCL communicator
+ *                on the ctx device;
+ *   then:        rsf_pool_allgather(ctx, send, count, recv): recv[r*count .. (r+1)*count) = rank r's
+ *                send[0..count) on every rank; rsf_pool_allreduce_sum: element-wise sum in place
+ *                (the summary path: sum q, sum q^2, counts — a few numbers instead of the pool).
+ * Buffers are in the ctx memory space like everywhere else; the collectives run on the ctx stream.
+ * RCCL is bound at run time (the copy already in the process — e.g. PyTorch's — else librccl.so.1;
+ * RSF_RCCL_LIB overrides).  world = 1 with id = NULL needs no RCCL (copies); with an id it is a real one-rank
+ * communicator.  The CPU oracle supports world = 1 only. */
+#define RSF_COMM_ID_BYTES 128
+int rsf_comm_unique_id(uint8_t id[RSF_COMM_ID_BYTES]);
+int rsf_comm_init(rsf_ctx *ctx, int32_t world, int32_t rank, const uint8_t id[RSF_COMM_ID_BYTES]);
+int rsf_comm_destroy(rsf_ctx *ctx);
+int rsf_pool_allgather(rsf_ctx *ctx, const double *send, int64_t count, double *recv);
+int rsf_pool_allreduce_sum(rsf_ctx *ctx, double *buf, int64_t count);
+
 /* The Philox4x32-10 block function itself (known-answer tests; Random123 vectors). */
 int rsf_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
 

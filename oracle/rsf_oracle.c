@@ -127,6 +127,7 @@ struct rsf_ctx {
   int32_t *wn;                  /* [C] samples in window */
   int64_t iters_done;
   int64_t n_acc, n_eval, n_nonfinite;
+  int32_t world;                /* 0: rsf_comm_init not called; the checker is single-process (world 1) */
 };
 
 int rsf_version(void) { return RSF_ABI_VERSION; }
@@ -706,6 +707,42 @@ int rsf_pool_kde(rsf_ctx *c, int64_t n, const double *x, int64_t stride, int32_t
     for (int64_t i = 0; i < n; ++i) { double dlt = grid[j] - x[i * stride]; acc += exp(-dlt * dlt * inv2c); }
     density[j] = acc * norm;
   }
+  return RSF_OK;
+}
+
+/* Pool collectives (include/rsf_abi.h): the checker is one process, so only world = 1 exists here —
+ * enough to run the same host code against both libraries. */
+int rsf_comm_unique_id(uint8_t id[RSF_COMM_ID_BYTES]) {
+  if (!id) return fail(RSF_ERR_INVALID, "rsf_comm_unique_id: NULL argument");
+  memset(id, 0, RSF_COMM_ID_BYTES);
+  return RSF_OK;
+}
+
+int rsf_comm_init(rsf_ctx *c, int32_t world, int32_t rank, const uint8_t id[RSF_COMM_ID_BYTES]) {
+  (void)id;
+  if (!c || world < 1 || rank < 0 || rank >= world) return fail(RSF_ERR_INVALID, "rsf_comm_init: bad argument");
+  if (c->world) return fail(RSF_ERR_STATE, "rsf_comm_init: this ctx already has a communicator (rsf_comm_destroy first)");
+  if (world > 1) return fail(RSF_ERR_UNSUPPORTED, "rsf_comm_init: the CPU oracle is single-process (world = 1 only)");
+  c->world = 1;
+  return RSF_OK;
+}
+
+int rsf_comm_destroy(rsf_ctx *c) {
+  if (!c) return fail(RSF_ERR_INVALID, "rsf_comm_destroy: NULL ctx");
+  c->world = 0;
+  return RSF_OK;
+}
+
+int rsf_pool_allgather(rsf_ctx *c, const double *send, int64_t count, double *recv) {
+  if (!c || !send || !recv || count < 1) return fail(RSF_ERR_INVALID, "rsf_pool_allgather: bad argument");
+  if (!c->world) return fail(RSF_ERR_STATE, "rsf_pool_allgather: call rsf_comm_init first");
+  if (recv != send) memmove(recv, send, (size_t)count * sizeof(double));
+  return RSF_OK;
+}
+
+int rsf_pool_allreduce_sum(rsf_ctx *c, double *buf, int64_t count) {
+  if (!c || !buf || count < 1) return fail(RSF_ERR_INVALID, "rsf_pool_allreduce_sum: bad argument");
+  if (!c->world) return fail(RSF_ERR_STATE, "rsf_pool_allreduce_sum: call rsf_comm_init first");
   return RSF_OK;
 }
 

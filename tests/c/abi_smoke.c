@@ -37,6 +37,17 @@ int main(void) {
   printf("mcmc %.17g %.17g %lld %lld %lld %lld\n", mean / C, ts[(ITERS - 1) * C], (long long)acc_n, (long long)eval_n,
          (long long)nonfinite, (long long)done);
   printf("backend %s version %d devices %d\n", rsf_backend(), rsf_version(), rsf_device_count());
+  /* posterior pool collectives with a one-rank communicator (in the HIP library: a real RCCL communicator) */
+  uint8_t id[RSF_COMM_ID_BYTES];
+  double pool[ITERS * C], sums[2] = {mean, 1.0};
+  CHECK(rsf_comm_unique_id(id));
+  CHECK(rsf_comm_init(ctx, 1, 0, id));
+  CHECK(rsf_pool_allgather(ctx, tq, ITERS * C, pool));
+  CHECK(rsf_pool_allreduce_sum(ctx, sums, 2));
+  int same = sums[0] == mean && sums[1] == 1.0;
+  for (int i = 0; i < ITERS * C; ++i) same = same && pool[i] == tq[i];
+  CHECK(rsf_comm_destroy(ctx));
+  printf("pool %s\n", same ? "ok" : "MISMATCH");
   CHECK(rsf_destroy(ctx));
   free(acc); free(data);
   return 0;

@@ -116,8 +116,33 @@ def test_header_compiles_as_c_and_runs_against_the_oracle(oracle_mod, tmp_path):
     subprocess.check_call(["gcc", "-std=c11", "-Wall", "-Werror", "-O1", "-o", str(exe), os.path.join(ROOT, "tests", "c", "abi_smoke.c"),
                            "-I" + os.path.join(ROOT, "include"), "-L" + odir, "-lrsf_oracle", "-lm", "-Wl,-rpath," + odir])
     out = subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split("\n")
-    assert out[0] == "nout 500" and out[3] == "backend oracle-cpu version 1 devices 0"
+    assert out[0] == "nout 500" and out[3] == "backend oracle-cpu version 1 devices 0" and out[4] == "pool ok"
     ssq = np.array(out[1].split()[1:], dtype=np.float64)
     assert ssq[1] < ssq[0] and ssq[1] < ssq[2] and np.isfinite(ssq).all()
     mean, std2, acc, ev, nonfinite, done = out[2].split()[1:]
     assert 800 < float(mean) < 1200 and float(std2) > 0 and int(ev) == 640 and int(done) == 10 and int(nonfinite) == 0
+
+
+def test_pool_collectives_call_order_and_single_rank(pkg, oracle_lib):
+    """rsf_comm_* / rsf_pool_allgather / rsf_pool_allreduce_sum on the checker: world = 1 is the identity, anything
+    before rsf_comm_init is a call-order error, and the single-process checker refuses world > 1."""
+    with pkg.Engine(lib=oracle_lib) as e:
+        x = np.arange(12.0).reshape(3, 4)
+        with pytest.raises(pkg.RsfError, match="comm_init"):
+            e.pool_allgather(x)
+        assert len(e.comm_unique_id()) == 128
+        with pytest.raises(pkg.RsfError, match="world = 1 only"):
+            e.comm_init(2, 0, bytes(128))
+        with pytest.raises(pkg.RsfError, match="bad argument"):
+            e.comm_init(1, 1)
+        e.comm_init(1, 0)
+        with pytest.raises(pkg.RsfError, match="already has a communicator"):
+            e.comm_init(1, 0)
+        out = e.pool_allgather(x)
+        assert out.shape == (1, 3, 4)
+        np.testing.assert_array_equal(out[0], x)
+        y = x.copy()
+        np.testing.assert_array_equal(e.pool_allreduce_sum(y), x)
+        e.comm_destroy()
+        with pytest.raises(pkg.RsfError, match="comm_init"):
+            e.pool_allreduce_sum(y)

@@ -130,6 +130,7 @@ def test_plain_c_caller(pkg, tmp_path):
                            "-Wl,-rpath," + csrc, "-Wl,-rpath,/opt/rocm/lib"])
     out = subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split("\n")
     assert out[0] == "nout 500" and out[3].startswith("backend hip-gfx950 version 1 devices")
+    assert "pool ok" in out  # (RCCL prints a version banner first) RCCL bound at run time from a process without PyTorch (the system librccl.so.1)
     c_ssq = np.array(out[1].split()[1:], dtype=np.float64)
     c_mcmc = out[2].split()[1:]
     model = pkg.RateStateModel(500)
@@ -146,3 +147,33 @@ def test_plain_c_caller(pkg, tmp_path):
     np.testing.assert_allclose(float(c_mcmc[0]), tq[-1, :, 0].mean(), rtol=1e-9)
     np.testing.assert_allclose(float(c_mcmc[1]), ts[-1, 0], rtol=1e-9)
     assert [int(v) for v in c_mcmc[2:]] == [st["accepted"], st["evaluated"], st["nonfinite"], st["iters_done"]]
+
+
+def test_bench_c_abi_pool_exchange_helper(pkg):
+    """bench.py's N > 1 leg pools the samples a second time through the C ABI (rsf_comm_init + rsf_pool_allgather,
+    the library's own RCCL communicator) under a watchdog thread.  One rank is all this box allows: a 1-rank NCCL
+    process group + a real 1-rank RCCL communicator inside the library."""
+    import socket
+    import sys
+
+    import torch
+    import torch.distributed as dist
+
+    from conftest import ROOT
+    from bayesian_markov_chain_monte_carlo_amd import dist as rdist
+
+    sys.path.insert(0, ROOT)
+    import bench
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+    try:
+        local = torch.arange(6 * 128, dtype=torch.float64, device="cuda").reshape(6, 128, 1)
+        pool = rdist.pool_to_chain_major(rdist.allgather_pool(local))
+        with pkg.Engine(mem="device") as e:
+            res = bench.abi_pool_allgather(e, local, pool, rdist, timeout_s=60.0)
+        assert res["status"] == "ok" and res["equals_torch_pool"] is True, res
+    finally:
+        dist.destroy_process_group()

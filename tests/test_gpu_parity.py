@@ -511,3 +511,31 @@ def test_device_memory_path_and_full_size_properties(pkg, oracle_mod, C, n, d, i
     assert 0.3 < acc_rate < 0.95
     assert np.isfinite(full[0]).all() and (full[1] > 0).all()
     assert full[0].shape == (iters, C, d)
+
+
+@pytest.mark.parametrize("mem", ["host", "device"])
+def test_pool_collectives_through_rccl_one_rank(pkg, mem):
+    """The C-ABI pool collectives with a REAL RCCL communicator (one rank — all a one-GPU box allows): the library
+    binds RCCL at run time, creates the communicator on the ctx device and runs ncclAllGather / ncclAllReduce on the
+    ctx stream.  Also the copy path (world = 1 without an id)."""
+    import torch
+
+    x = np.arange(5000.0).reshape(10, 500)
+    for with_id in (True, False):
+        with pkg.Engine(mem=mem) as e:
+            uid = e.comm_unique_id() if with_id else None
+            if with_id:
+                assert len(uid) == 128 and any(uid)
+            e.comm_init(1, 0, uid)
+            xin = torch.from_numpy(x).cuda() if mem == "device" else x
+            out = e.pool_allgather(xin)
+            y = e.pool_allreduce_sum(torch.from_numpy(x).cuda() if mem == "device" else x.copy())
+            e.sync()
+            out = out.cpu().numpy() if mem == "device" else out
+            y = y.cpu().numpy() if mem == "device" else y
+            assert out.shape == (1, 10, 500)
+            np.testing.assert_array_equal(out[0], x)
+            np.testing.assert_array_equal(y, x)
+            e.comm_destroy()
+            with pytest.raises(pkg.RsfError, match="comm_init"):
+                e.pool_allgather(xin)
