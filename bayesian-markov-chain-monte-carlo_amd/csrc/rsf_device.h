@@ -26,6 +26,7 @@ struct Consts {
   double h, hh, h6;               // RK4 step, h/2, h/6
   double inv_dt;                  // 1 / delta_t
   double t0, dt;                  // t_start, delta_t
+  double cacc;                    // (h/6)/delta_t: acceleration sample = cacc * (k1 + 2 k2 + 2 k3 + k4)_V summed over the interval
   const double *vl;               // V_l at stage times t_start + j*h/2, j = 0 .. 2*S*(nout-1)
   const double *data;             // observation [nout] (of this workgroup's chain group) or nullptr
   int64_t group_chains;           // chains per observation group (0: one series for all)
@@ -48,8 +49,11 @@ struct Lane {
   double inv_dc;  // 1/Dc
   double kprime;  // k'
   double kia;     // k'/a          : d(mu)/a = kia * d(ms)
+  double khh, kh, kh6;  // kia*(h/2), kia*h, kia*(h/6): d(mu)/a of a stage / step straight from the ms derivative
   double k1k;     // k1/k'         : radiation damping in ms units
   double via;     // V_ref/a
+  double vk, vb;  // (V_ref/a) k', (V_ref/a) b/Dc : dV/dt = w (vk d0 - vb d1/x)
+  double c3;      // vb - vk V_ref : coefficient of w in that bracket once d0 and d1/x are written out (rhs_fast)
   double bdc;     // b/Dc          : b/theta = bdc / x
   double boa;     // b/a
   double tc;      // -mu_ref/a
@@ -67,9 +71,15 @@ __device__ __forceinline__ Lane make_lane(double dc, double a, double b, const C
   L.inv_dc = 1.0 / dc;
   L.kprime = (1e-2 * 10) / dc;
   L.kia = L.kprime * inv_a;
+  L.khh = L.kia * K.hh;
+  L.kh = L.kia * K.h;
+  L.kh6 = L.kia * K.h6;
   L.k1k = K.k1 / L.kprime;
   L.via = K.V_ref * inv_a;
   L.bdc = b * L.inv_dc;
+  L.vk = L.via * L.kprime;
+  L.vb = L.via * L.bdc;
+  L.c3 = __builtin_fma(-L.vk, K.V_ref, L.vb);
   L.boa = b * inv_a;
   L.tc = -K.mu_ref * inv_a;
   L.hhd = K.hh * L.inv_dc;
@@ -98,13 +108,32 @@ __device__ __forceinline__ void rhs_tail(double w, double rx, double x, double v
                                          const Consts &K, double &d0, double &d1, double &d2) {
   d1 = __builtin_fma(-w, x, 1.0);                    // ageing law: 1 - v*theta/Dc
   d0 = __builtin_fma(-K.V_ref, w, vl);               // spring loading / k':  V_l - v
-  const double bt = (L.bdc * d1) * rx;               // b/theta * dtheta/dt
-  const double va = w * L.via;                       // v/a
-  d2 = va * __builtin_fma(L.kprime, d0, -bt);        // v/a (dmu/dt - b/theta dtheta/dt), RateStateModel.py:346
-  if (DAMP) {                                        // one fixed-point pass, RateStateModel.py:349-353
-    d0 = __builtin_fma(-L.k1k, d2, d0);
-    d2 = va * __builtin_fma(L.kprime, d0, -bt);
+  const double bt = (L.vb * d1) * rx;                // (V_ref/a) b/theta * dtheta/dt
+  double in = __builtin_fma(L.vk, d0, -bt);          // dV/dt = w * in:  v/a (dmu/dt - b/theta dtheta/dt), RateStateModel.py:346
+  if (DAMP) {                                        // one fixed-point pass, RateStateModel.py:349-353: d0 -= k1/k' * dV/dt,
+    d0 = __builtin_fma(-(L.k1k * w), in, d0);        //   then dV/dt again; the first dV/dt = w * in is never formed, which
+    in = __builtin_fma(L.vk, d0, -bt);               //   keeps the chain d1 -> bt -> in -> d0 one instruction shorter
   }
+  d2 = w * in;
+}
+
+// The same RHS arranged for the hot loop, where w arrives last (it ends the dependency chain of the previous stage):
+// with d1/x = 1/x - w the bracket of dV/dt is LINEAR in w,
+//     in = vk (V_l - V_ref w) - vb (1/x - w) = (vk V_l - vb/x) + (vb - vk V_ref) w,
+// so everything but one fma is ready before w is, and the damped d0 follows two instructions after w instead of
+// five.  (vb/x and vb w nearly cancel, but against vk V_l their rounding is ~3e-17 of the result.)
+template <bool DAMP>
+__device__ __forceinline__ void rhs_fast(double w, double rx, double x, double vl, const Lane &L,
+                                         const Consts &K, double &d0, double &d1, double &d2) {
+  d1 = __builtin_fma(-w, x, 1.0);
+  d0 = __builtin_fma(-K.V_ref, w, vl);
+  double in = __builtin_fma(L.c3, w, __builtin_fma(-L.vb, rx, L.vk * vl));
+  if (DAMP) {  // d0 -= k1/k' * (w in); then in again with the damped d0: in - vk (k1/k' w) in
+    const double kw = L.k1k * w;
+    d0 = __builtin_fma(-kw, in, d0);
+    in = __builtin_fma(-(L.vk * kw), in, in);
+  }
+  d2 = w * in;
 }
 
 // (w, 1/x) by full evaluation
@@ -119,18 +148,35 @@ __device__ __forceinline__ void eval_full(double ms, double x, const Lane &L, co
 }
 
 // (w', 1/x') at (ms + dms, x1 = x + dx) from (w, rx) at (ms, x).  With rho = dx/x (= dtheta/theta) and
-// dlt = dmu/a - (b/a) log1p(rho), dmu/a = kia*dms:   w' = w exp(dlt),   1/x' = (1/x)/(1 + rho),
+// dlt = dk - (b/a) log1p(rho), dk = dmu/a = kia*dms:   w' = w exp(dlt),   1/x' = (1/x)/(1 + rho),
 // by short series — the same function of (ms', x') to rounding inside the tier's guard region:
 //   tier     |rho| <   |dlt| <   log1p to     expm1 to       1/x'                              truncation
-//   TIGHT    2^-20     2^-9      rho^2/2      dlt^5/120      1st-order start + 1 Newton step   < 3e-19, rho^4 < 2^-80
+//   TIGHT    2^-20     2^-9      rho^2/2      dlt^5/120      1 - rho + rho^2 (no Newton step)  < 3e-19, rho^3 < 2^-60
 //   NARROW   2^-9      2^-6      rho^6/6      dlt^7/5040     2nd-order start + 1 Newton step   < 1e-19, rho^6 < 2^-54
 //   WIDE     2^-7      2^-6      rho^7/7      dlt^7/5040     1st-order start + 2 Newton steps  < 1e-19, rho^8 < 2^-56
-// Guard tracks the largest |rho| / |dlt| seen since it was last reset.
+// Guard tracks the largest |rho| / |dlt| seen since it was last reset — through the HIGH WORD of each double read as
+// a float: for |x| < 2^1017 that reading is finite and monotone in |x|, the thresholds are powers of two (exact in the
+// high word), and two values fold into one v_max3_f32 with |.| as source modifiers (4 instructions per step instead
+// of 8 v_max_f64).  |x| >= 2^1017, Inf and NaN read as float NaNs, which max ignores: NaN passes through as it always
+// did (a dead trajectory stays on the fast path and ends in a non-finite SSq), and an increment that large can only
+// come out of a state that is already beyond 1e150 — whose sum of squares rejects the proposal whichever path
+// integrates it.  (Testing w for Inf at the end of the pair instead put five dependent instructions between the last
+// result and the loop branch: +3 % at cfg1.)
 enum Tier : int { TIGHT = 0, NARROW = 1, WIDE = 2 };
 
+#ifdef RSF_GUARD_F64
 struct Guard {
   double rho, dlt;
 };
+#else
+struct Guard {
+  float rho, dlt;
+};
+#endif
+
+__device__ __forceinline__ float hi_as_float(double x) { return __builtin_bit_cast(float, __double2hiint(x)); }
+constexpr float hi_pow2(int e) { return __builtin_bit_cast(float, (1023 + e) << 20); }  // high word of 2^e, as float
+
 
 // leading series coefficients of a tier (kept in VGPRs, see Lane)
 template <int T>
@@ -141,10 +187,15 @@ __device__ __forceinline__ void set_tier(Lane &L) {
 }
 
 template <int T>
-__device__ __forceinline__ void eval_incr(double dms, double dx, double x1, const Lane &L, double w0, double rx0,
-                                          double &w, double &rx, Guard &g) {
-  const double rho = dx * rx0;
+__device__ __forceinline__ void eval_incr(double kf, double dms_dt, double R, double dth_dt, double x1, const Lane &L, double w0,
+                                          double rx0, double &w, double &rx, Guard &g) {
+  // dk = kf * dms_dt (kf: kia times the step fraction);  rho = R * dth_dt (R: step fraction / Dc / x, once per step)
+  const double rho = dth_dt * R;
+#ifdef RSF_GUARD_F64
   g.rho = __builtin_fmax(g.rho, __builtin_fabs(rho));
+#else
+  g.rho = __builtin_fmaxf(g.rho, __builtin_fabsf(hi_as_float(rho)));
+#endif
   double p;
   if (T == TIGHT) {
     p = __builtin_fma(rho, -0.5, 1.0);
@@ -160,8 +211,12 @@ __device__ __forceinline__ void eval_incr(double dms, double dx, double x1, cons
     p = __builtin_fma(p, rho, -0.5);
     p = __builtin_fma(p, rho, 1.0);
   }
-  const double dlt = __builtin_fma(-L.boa, p * rho, dms * L.kia);
+  const double dlt = __builtin_fma(-(L.boa * rho), p, kf * dms_dt);  // d1 -> rho -> p -> dlt: three deep
+#ifdef RSF_GUARD_F64
   g.dlt = __builtin_fmax(g.dlt, __builtin_fabs(dlt));
+#else
+  g.dlt = __builtin_fmaxf(g.dlt, __builtin_fabsf(hi_as_float(dlt)));
+#endif
   double e;
   if (T == TIGHT) {
     e = L.c_em1;
@@ -173,7 +228,7 @@ __device__ __forceinline__ void eval_incr(double dms, double dx, double x1, cons
   e = fm::hfma(e, dlt, 1.0 / 6.0);
   e = __builtin_fma(e, dlt, 0.5);
   e = __builtin_fma(e, dlt, 1.0);
-  w = __builtin_fma(w0, e * dlt, w0);
+  w = __builtin_fma(w0 * dlt, e, w0);  // w0*dlt is off the critical path (e is the late operand)
   if (T == WIDE) {
     rx = __builtin_fma(-rho, rx0, rx0);
     rx = __builtin_fma(rx, __builtin_fma(-x1, rx, 1.0), rx);
@@ -182,14 +237,18 @@ __device__ __forceinline__ void eval_incr(double dms, double dx, double x1, cons
     rx = __builtin_fma(rx0, __builtin_fma(rho, rho, -rho), rx0);
     rx = __builtin_fma(rx, __builtin_fma(-x1, rx, 1.0), rx);
   } else {
-    rx = __builtin_fma(-rho, rx0, rx0);
-    rx = __builtin_fma(rx, __builtin_fma(-x1, rx, 1.0), rx);
+    rx = __builtin_fma(rx0, __builtin_fma(rho, rho, -rho), rx0);  // exact to rounding for |rho| < 2^-20; like w, resynced
   }
 }
 
 template <int T>
-__device__ __forceinline__ bool guard_ok(const Guard &g) {  // false for Inf; NaN passes through
+__device__ __forceinline__ bool guard_ok(const Guard &g) {  // NaN passes through (see Guard)
+#ifdef RSF_GUARD_F64
   return (g.rho < (T == WIDE ? 0x1.0p-7 : (T == NARROW ? 0x1.0p-9 : 0x1.0p-20))) && (g.dlt < (T == TIGHT ? 0x1.0p-9 : 0x1.0p-6));
+#else
+  return (g.rho < (T == WIDE ? hi_pow2(-7) : (T == NARROW ? hi_pow2(-9) : hi_pow2(-20)))) &&
+         (g.dlt < (T == TIGHT ? hi_pow2(-9) : hi_pow2(-6)));
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -208,9 +267,12 @@ __device__ __forceinline__ bool guard_ok(const Guard &g) {  // false for Inf; Na
 #define RSF_RESYNC 128
 #endif
 
+// Both step functions return the weighted sum of the V derivatives, k1 + 2 k2 + 2 k3 + k4: the velocity increment of
+// the step is (h/6) times it.  V itself never feeds back into the RHS, so the hot loop does not carry it: with one
+// step per output sample the acceleration (V_k - V_{k-1})/delta_t (RateStateModel.py:388) IS cacc * sum.
 template <bool DAMP>
-__device__ __forceinline__ void rk4_cold(State &s, double vl0, double vlm, double vl1, const Lane &L,
-                                         const Consts &K) {
+__device__ __forceinline__ double rk4_cold(State &s, double vl0, double vlm, double vl1, const Lane &L,
+                                           const Consts &K) {
   double k0 = 0.0, k1 = 0.0, s0 = 0.0, s1 = 0.0, s2 = 0.0;
 #pragma nounroll
   for (int st = 0; st < 4; ++st) {
@@ -229,32 +291,33 @@ __device__ __forceinline__ void rk4_cold(State &s, double vl0, double vlm, doubl
   }
   s.ms = __builtin_fma(K.h6, s0, s.ms);
   s.x = __builtin_fma(L.h6d, s1, s.x);
-  s.V = __builtin_fma(K.h6, s2, s.V);
+  return s2;
 }
 
 template <bool DAMP, int T>
-__device__ __forceinline__ void rk4_fast(State &s, double vl0, double vlm, double vl1, const Lane &L,
-                                         const Consts &K, Guard &g) {
-  double a0, a1, a2, b0, b1, b2, c0, c1, c2, e0, e1, e2, w, rx;
-  rhs_tail<DAMP>(s.w, s.rx, s.x, vl0, L, K, a0, a1, a2);
-  double dx = L.hhd * a1;
-  eval_incr<T>(K.hh * a0, dx, s.x + dx, L, s.w, s.rx, w, rx, g);
-  rhs_tail<DAMP>(w, rx, s.x + dx, vlm, L, K, b0, b1, b2);
-  dx = L.hhd * b1;
-  eval_incr<T>(K.hh * b0, dx, s.x + dx, L, s.w, s.rx, w, rx, g);
-  rhs_tail<DAMP>(w, rx, s.x + dx, vlm, L, K, c0, c1, c2);
-  dx = L.hd * c1;
-  eval_incr<T>(K.h * c0, dx, s.x + dx, L, s.w, s.rx, w, rx, g);
-  rhs_tail<DAMP>(w, rx, s.x + dx, vl1, L, K, e0, e1, e2);
-  const double dms = K.h6 * (a0 + 2.0 * b0 + 2.0 * c0 + e0);
-  dx = L.h6d * (a1 + 2.0 * b1 + 2.0 * c1 + e1);
-  const double x1 = s.x + dx;
-  eval_incr<T>(dms, dx, x1, L, s.w, s.rx, w, rx, g);
-  s.ms = s.ms + dms;
+__device__ __forceinline__ double rk4_fast(State &s, double vl0, double vlm, double vl1, const Lane &L,
+                                           const Consts &K, Guard &g) {
+  double a0, a1, a2, b0, b1, b2, c0, c1, c2, e0, e1, e2, w, rx, xs;
+  const double Rh = L.hhd * s.rx, Rf = Rh + Rh, R6 = L.h6d * s.rx;  // rho of a stage = its theta derivative times these
+  rhs_fast<DAMP>(s.w, s.rx, s.x, vl0, L, K, a0, a1, a2);
+  xs = __builtin_fma(L.hhd, a1, s.x);
+  eval_incr<T>(L.khh, a0, Rh, a1, xs, L, s.w, s.rx, w, rx, g);
+  rhs_fast<DAMP>(w, rx, xs, vlm, L, K, b0, b1, b2);
+  xs = __builtin_fma(L.hhd, b1, s.x);
+  eval_incr<T>(L.khh, b0, Rh, b1, xs, L, s.w, s.rx, w, rx, g);
+  rhs_fast<DAMP>(w, rx, xs, vlm, L, K, c0, c1, c2);
+  xs = __builtin_fma(L.hd, c1, s.x);
+  eval_incr<T>(L.kh, c0, Rf, c1, xs, L, s.w, s.rx, w, rx, g);
+  rhs_fast<DAMP>(w, rx, xs, vl1, L, K, e0, e1, e2);
+  const double t0 = a0 + 2.0 * b0 + 2.0 * c0 + e0;
+  const double t1 = a1 + 2.0 * b1 + 2.0 * c1 + e1;
+  const double x1 = __builtin_fma(L.h6d, t1, s.x);
+  eval_incr<T>(L.kh6, t0, R6, t1, x1, L, s.w, s.rx, w, rx, g);
+  s.ms = __builtin_fma(K.h6, t0, s.ms);
   s.x = x1;
-  s.V = s.V + K.h6 * (a2 + 2.0 * b2 + 2.0 * c2 + e2);
   s.w = w;
   s.rx = rx;
+  return a2 + 2.0 * b2 + 2.0 * c2 + e2;
 }
 
 // advance one step; `resync` (wave-uniform, from the step index) asks for a full re-evaluation of (w, 1/th) first
@@ -262,18 +325,19 @@ template <bool DAMP>
 __device__ __forceinline__ void rk4_step(State &s, bool resync, double vl0, double vlm, double vl1, const Lane &L,
                                          const Consts &K) {
 #ifdef RSF_NO_INCREMENTAL
-  rk4_cold<DAMP>(s, vl0, vlm, vl1, L, K);
+  s.V = __builtin_fma(K.h6, rk4_cold<DAMP>(s, vl0, vlm, vl1, L, K), s.V);
   (void)resync;
 #else
   if (resync) eval_full(s.ms, s.x, L, K, s.w, s.rx);
   const State save = s;
-  Guard g = {0.0, 0.0};
-  rk4_fast<DAMP, WIDE>(s, vl0, vlm, vl1, L, K, g);
+  Guard g = {0, 0};
+  double dv = rk4_fast<DAMP, WIDE>(s, vl0, vlm, vl1, L, K, g);
   if (__builtin_expect(!guard_ok<WIDE>(g), 0)) {  // an increment too large (or Inf; NaN passes through): cold path
     s = save;
-    rk4_cold<DAMP>(s, vl0, vlm, vl1, L, K);
+    dv = rk4_cold<DAMP>(s, vl0, vlm, vl1, L, K);
     eval_full(s.ms, s.x, L, K, s.w, s.rx);
   }
+  s.V = __builtin_fma(K.h6, dv, save.V);
 #endif
 }
 
@@ -330,6 +394,17 @@ __device__ __forceinline__ void emit_at(double vnow, double vprev, int ko, doubl
   }
 }
 
+// the same sample straight from the step's derivative sum (one step per output sample): ak = cacc * dvs
+template <bool WANT_SSQ, bool WANT_ACC>
+__device__ __forceinline__ void emit_incr(double dvs, int ko, double obs, const Consts &K, int k0, double &ssq,
+                                          double *acc_out, int64_t stride) {
+  if (WANT_ACC) acc_out[(int64_t)(k0 + ko) * stride] = dvs * K.cacc;
+  if (WANT_SSQ) {
+    const double r = __builtin_fma(dvs, K.cacc, -obs);  // one rounding; identical with and without WANT_ACC
+    ssq = __builtin_fma(r, r, ssq);
+  }
+}
+
 template <bool WANT_SSQ, bool WANT_ACC>
 __device__ __forceinline__ void emit_sample(double vnow, Emit &em, double obs, const Consts &K, int k0, double &ssq,
                                             double *acc_out, int64_t stride) {
@@ -349,25 +424,25 @@ __device__ __forceinline__ int integrate_pairs(const double *lds, const double *
     const double obs0 = WANT_SSQ ? ld[S1 ? r : em.ko] : 0.0, obs1 = (WANT_SSQ && S1) ? ld[r + 1] : 0.0;
     if ((r & (RSF_RESYNC - 1)) == 0) eval_full(s.ms, s.x, L, K, s.w, s.rx);
     const State save = s;
-    Guard g = {0.0, 0.0};
-    rk4_fast<DAMP, T>(s, v[0], v[1], v[2], L, K, g);
-    double vmid = s.V;
-    rk4_fast<DAMP, T>(s, v[2], v[3], v[4], L, K, g);
+    Guard g = {0, 0};
+    double dv0 = rk4_fast<DAMP, T>(s, v[0], v[1], v[2], L, K, g);
+    double dv1 = rk4_fast<DAMP, T>(s, v[2], v[3], v[4], L, K, g);
     const bool bad = !guard_ok<T>(g);
     const unsigned long long badmask = __builtin_amdgcn_ballot_w64(bad);  // wave-uniform, straight from the compares
     if (__builtin_expect(badmask != 0, 0)) {  // scalar branch: the hot path carries no exec-mask bookkeeping
       if (bad) {
         s = save;
-        rk4_cold<DAMP>(s, v[0], v[1], v[2], L, K);
-        vmid = s.V;
-        rk4_cold<DAMP>(s, v[2], v[3], v[4], L, K);
+        dv0 = rk4_cold<DAMP>(s, v[0], v[1], v[2], L, K);
+        dv1 = rk4_cold<DAMP>(s, v[2], v[3], v[4], L, K);
         eval_full(s.ms, s.x, L, K, s.w, s.rx);
       }
     }
-    if (S1) {  // sample index == step index: no bookkeeping
-      emit_at<WANT_SSQ, WANT_ACC>(vmid, save.V, r, obs0, K, k0, ssq, acc_out, stride);
-      emit_at<WANT_SSQ, WANT_ACC>(s.V, vmid, r + 1, obs1, K, k0, ssq, acc_out, stride);
+    if (S1) {  // sample index == step index: no bookkeeping, and V is not carried at all
+      emit_incr<WANT_SSQ, WANT_ACC>(dv0, r, obs0, K, k0, ssq, acc_out, stride);
+      emit_incr<WANT_SSQ, WANT_ACC>(dv1, r + 1, obs1, K, k0, ssq, acc_out, stride);
     } else {
+      const double vmid = __builtin_fma(K.h6, dv0, save.V);
+      s.V = __builtin_fma(K.h6, dv1, vmid);
       if (++em.phase == K.S) { em.phase = 0; emit_sample<WANT_SSQ, WANT_ACC>(vmid, em, obs0, K, k0, ssq, acc_out, stride); }
       if (++em.phase == K.S) { em.phase = 0; emit_sample<WANT_SSQ, WANT_ACC>(s.V, em, obs0, K, k0, ssq, acc_out, stride); }
     }
@@ -396,11 +471,15 @@ __device__ __forceinline__ void integrate_tiers(const double *lds, const double 
   r = integrate_pairs<DAMP, WANT_SSQ, WANT_ACC, WIDE, S1>(lds, ld, K, L, k0, r, nsteps, s, em, ssq, acc_out, stride);
   if (r < nsteps) {  // odd last step of the chunk: one full-evaluation step (it always completes a sample)
     const double *v = lds + 2 * r;
-    const double vprev = S1 ? s.V : em.vprev;
     const double obs = WANT_SSQ ? ld[kn - 1] : 0.0;
-    rk4_cold<DAMP>(s, v[0], v[1], v[2], L, K);
+    const double dv = rk4_cold<DAMP>(s, v[0], v[1], v[2], L, K);
     eval_full(s.ms, s.x, L, K, s.w, s.rx);
-    emit_at<WANT_SSQ, WANT_ACC>(s.V, vprev, kn - 1, obs, K, k0, ssq, acc_out, stride);
+    if (S1) {
+      emit_incr<WANT_SSQ, WANT_ACC>(dv, kn - 1, obs, K, k0, ssq, acc_out, stride);
+    } else {
+      s.V = __builtin_fma(K.h6, dv, s.V);
+      emit_at<WANT_SSQ, WANT_ACC>(s.V, em.vprev, kn - 1, obs, K, k0, ssq, acc_out, stride);
+    }
   }
 }
 

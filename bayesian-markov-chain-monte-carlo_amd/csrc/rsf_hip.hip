@@ -52,6 +52,12 @@ int fail(int code, const char *fmt, ...) {
 enum Mode : int { RK4_F64 = 0, RK4_F32 = 1, DOP853 = 2 };  // how the ODE is integrated (rsf_model.flags)
 
 constexpr int kMaxBlock = 256;           // 4 waves: one per SIMD of a CU
+// Register budget of the RK4 sampler kernel: at least this many workgroups per CU, i.e. waves per SIMD (2 => at most
+// 256 of the 512 unified registers per lane).  cfg2 runs 4 waves per SIMD worth of chains, so a kernel that drifts
+// above 256 registers would run it in four rounds instead of two.  The DOP853 mode (12 stage vectors) is not bounded.
+#ifndef RSF_MIN_BLOCKS
+#define RSF_MIN_BLOCKS 2
+#endif
 constexpr size_t kLdsBudget = 32 * 1024; // per workgroup; 4 workgroups/CU still fit in 160 KiB
 
 // ---------------------------------------------------------------------------------------------
@@ -265,7 +271,7 @@ struct McmcArgs {
 };
 
 template <int D, bool DAMP, bool REPLAY, int MODE>
-__global__ void __launch_bounds__(kMaxBlock) mcmc_kernel(Consts K, McmcArgs A) {
+__global__ void __launch_bounds__(kMaxBlock, MODE == DOP853 ? 1 : RSF_MIN_BLOCKS) mcmc_kernel(Consts K, McmcArgs A) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   rsf::select_group(K);
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -644,6 +650,7 @@ Consts make_consts(const rsf_ctx *c, const double *data) {
   K.a_def = c->m.a; K.b_def = c->m.b;
   K.h = c->h; K.hh = 0.5 * c->h; K.h6 = c->h / 6.0;
   K.inv_dt = 1.0 / c->delta_t;
+  K.cacc = K.h6 * K.inv_dt;
   K.t0 = c->m.t_start;
   K.dt = c->delta_t;
   K.vl = (const double *)c->vl.p;

@@ -17,7 +17,9 @@ __global__ void __launch_bounds__(256) bench(double *out, unsigned long long *cy
   double r[ILP];
 #pragma unroll
   for (int i = 0; i < ILP; ++i) r[i] = seed + i * 1e-3 + threadIdx.x * 1e-6;
-  const double a = 1.0000001, b = 1e-9;
+  const double a = 1.0000001, b = 1e-9, c3 = 0.5 + seed;
+  float gf = 0.0f;
+  double r2[ILP];
   unsigned long long t0, t1, r0, r1;
   asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(r0)::"memory");
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");
@@ -37,6 +39,12 @@ __global__ void __launch_bounds__(256) bench(double *out, unsigned long long *cy
         if (OP == 8) { float f = (float)r[i]; asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(f)); r[i] = f; }
         if (OP == 9) asm volatile("v_fmac_f64 %0, %1, %2" : "+v"(r[i]) : "v"(a), "v"(b));
         if (OP == 10) asm volatile("s_nop 0\n\tv_fma_f64 %0, %0, %1, %2" : "+v"(r[i]) : "v"(a), "v"(b));
+        if (OP == 12) asm volatile("v_fma_f64 %0, %0, %1, %2" : "+v"(r[i]) : "v"(a), "s"(b));        // one SGPR source
+        if (OP == 13) asm volatile("v_fma_f64 %0, %0, %1, 1.0" : "+v"(r[i]) : "v"(a));               // inline constant
+        if (OP == 14) asm volatile("v_fma_f64 %0, %1, %2, %3" : "=v"(r[i]) : "v"(a), "v"(b), "v"(c3)); // no dependence at all
+        if (OP == 15) asm volatile("v_mul_f64 %0, %1, %2" : "=v"(r[i]) : "v"(a), "v"(b));
+        if (OP == 16) { float f = __builtin_bit_cast(float, __double2hiint(r[i])); asm volatile("v_max3_f32 %0, %0, |%1|, |%1|" : "+v"(gf) : "v"(f)); asm volatile("v_fma_f64 %0, %0, %1, %2" : "+v"(r[i]) : "v"(a), "v"(b)); }  // fma + max3 on its high word: 2 instrs
+        if (OP == 17) { asm volatile("v_fma_f64 %0, %0, %1, %2" : "+v"(r[i]) : "v"(a), "v"(b)); asm volatile("v_mul_f64 %0, %1, %1" : "=v"(r2[i]) : "v"(r[i])); }  // fma then a directly dependent mul: 2 instrs
         if (OP == 11) { int lo = __double2loint(r[i]); asm volatile("v_cndmask_b32 %0, %0, %0, vcc" : "+v"(lo)); r[i] = __hiloint2double(__double2hiint(r[i]), lo); }
       }
     }
@@ -45,7 +53,8 @@ __global__ void __launch_bounds__(256) bench(double *out, unsigned long long *cy
   asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(r1)::"memory");
   double s = 0;
 #pragma unroll
-  for (int i = 0; i < ILP; ++i) s += r[i];
+  for (int i = 0; i < ILP; ++i) s += r[i] + ((OP == 17) ? r2[i] : 0.0);
+  s += gf;
   out[blockIdx.x * blockDim.x + threadIdx.x] = s;
   if (threadIdx.x == 0) { cyc[blockIdx.x] = t1 - t0; rt[blockIdx.x] = r1 - r0; }
 }
@@ -87,7 +96,19 @@ int run(const char *name, int waves_per_simd) {
   return 0;
 }
 
-int main() {
+int main(int argc, char **argv) {
+  if (argc > 1) {  // lone-wave issue cost by instruction form (cycles per wave-instruction; OP 16/17 count 2 per slot)
+    run<0, 4, 64>("fma v,v,v,v", 1); run<0, 8, 64>("fma v,v,v,v", 1); run<0, 16, 64>("fma v,v,v,v", 1);
+    run<12, 4, 64>("fma v,v,v,s", 1); run<12, 8, 64>("fma v,v,v,s", 1);
+    run<13, 4, 64>("fma v,v,v,1.0", 1); run<13, 8, 64>("fma v,v,v,1.0", 1);
+    run<14, 8, 64>("fma indep", 1); run<15, 8, 64>("mul indep", 1);
+    run<1, 4, 64>("mul v,v,v", 1); run<1, 8, 64>("mul v,v,v", 1);
+    run<2, 8, 64>("add v,v,v", 1); run<9, 8, 64>("fmac", 1);
+    run<16, 4, 64>("fma+max3hi", 1); run<16, 8, 64>("fma+max3hi", 1);
+    run<17, 4, 64>("fma+depmul", 1); run<17, 8, 64>("fma+depmul", 1);
+    run<0, 8, 64>("fma v,v,v,v", 2); run<14, 8, 64>("fma indep", 2);
+    return 0;
+  }
   // does the SIMD skip inactive 16/32-lane groups of a wave64 for fp64 ops?
   run<0, 1, 64>("v_fma_f64", 1); run<0, 4, 64>("v_fma_f64", 1);
   run<0, 1, 32>("v_fma_f64", 1); run<0, 4, 32>("v_fma_f64", 1);
