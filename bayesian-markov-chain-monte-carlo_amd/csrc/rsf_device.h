@@ -26,6 +26,7 @@ struct Consts {
   double h, hh, h6;               // RK4 step, h/2, h/6
   double inv_dt;                  // 1 / delta_t
   double t0, dt;                  // t_start, delta_t
+  double inv_vref;                // 1/V_ref
   double cacc;                    // (h/6)/delta_t: acceleration sample = cacc * (k1 + 2 k2 + 2 k3 + k4)_V summed over the interval
   const double *vl;               // V_l at stage times t_start + j*h/2, j = 0 .. 2*S*(nout-1)
   const double *data;             // observation [nout] (of this workgroup's chain group) or nullptr
@@ -67,14 +68,20 @@ __device__ __forceinline__ void set_tier(Lane &L);
 
 __device__ __forceinline__ Lane make_lane(double dc, double a, double b, const Consts &K) {
   Lane L;
+  // reciprocals by rsf_math.h (<= 1 ulp from the IEEE quotient at a fifth of its instruction count)
+#ifdef RSF_MATH_OCML
   const double inv_a = 1.0 / a;
   L.inv_dc = 1.0 / dc;
-  L.kprime = (1e-2 * 10) / dc;
+#else
+  const double inv_a = fm::rcp(a);
+  L.inv_dc = fm::rcp(dc);
+#endif
+  L.kprime = (1e-2 * 10) * L.inv_dc;
   L.kia = L.kprime * inv_a;
   L.khh = L.kia * K.hh;
   L.kh = L.kia * K.h;
   L.kh6 = L.kia * K.h6;
-  L.k1k = K.k1 / L.kprime;
+  L.k1k = (K.k1 * dc) * (1.0 / (1e-2 * 10));  // k1/k'
   L.via = K.V_ref * inv_a;
   L.bdc = b * L.inv_dc;
   L.vk = L.via * L.kprime;
@@ -343,8 +350,8 @@ __device__ __forceinline__ void rk4_step(State &s, bool resync, double vl0, doub
 
 __device__ __forceinline__ State initial_state(double dc, const Lane &L, const Consts &K) {
   State s;
-  s.ms = K.mu0 / L.kprime;             // mu(0) = mu_t_zero, RateStateModel.py:367-377
-  s.x = (dc / K.V_ref) * L.inv_dc;     // theta(0) = Dc/V_ref
+  s.ms = (K.mu0 * dc) * (1.0 / (1e-2 * 10));  // mu(0)/k' = mu_t_zero/k', RateStateModel.py:367-377
+  s.x = (dc * K.inv_vref) * L.inv_dc;         // theta(0)/Dc = (Dc/V_ref)/Dc
   s.V = K.V_ref;
   eval_full(s.ms, s.x, L, K, s.w, s.rx);
   return s;
@@ -469,11 +476,19 @@ __device__ __forceinline__ void integrate_tiers(const double *lds, const double 
   if (tier == TIGHT) r = integrate_pairs<DAMP, WANT_SSQ, WANT_ACC, TIGHT, S1>(lds, ld, K, L, k0, r, nsteps, s, em, ssq, acc_out, stride);
   if (tier <= NARROW) r = integrate_pairs<DAMP, WANT_SSQ, WANT_ACC, NARROW, S1>(lds, ld, K, L, k0, r, nsteps, s, em, ssq, acc_out, stride);
   r = integrate_pairs<DAMP, WANT_SSQ, WANT_ACC, WIDE, S1>(lds, ld, K, L, k0, r, nsteps, s, em, ssq, acc_out, stride);
-  if (r < nsteps) {  // odd last step of the chunk: one full-evaluation step (it always completes a sample)
+  if (r < nsteps) {  // odd last step of the chunk (it always completes a sample): one WIDE step, cold if its guard trips
     const double *v = lds + 2 * r;
     const double obs = WANT_SSQ ? ld[kn - 1] : 0.0;
-    const double dv = rk4_cold<DAMP>(s, v[0], v[1], v[2], L, K);
-    eval_full(s.ms, s.x, L, K, s.w, s.rx);
+    Lane Lw = L;
+    set_tier<WIDE>(Lw);
+    const State save = s;
+    Guard g = {0, 0};
+    double dv = rk4_fast<DAMP, WIDE>(s, v[0], v[1], v[2], Lw, K, g);
+    if (__builtin_expect(!guard_ok<WIDE>(g), 0)) {
+      s = save;
+      dv = rk4_cold<DAMP>(s, v[0], v[1], v[2], L, K);
+      eval_full(s.ms, s.x, L, K, s.w, s.rx);
+    }
     if (S1) {
       emit_incr<WANT_SSQ, WANT_ACC>(dv, kn - 1, obs, K, k0, ssq, acc_out, stride);
     } else {
@@ -568,19 +583,34 @@ __device__ __forceinline__ double u53(uint32_t hi, uint32_t lo) {
   return (double)(k + 1) * 0x1.0p-53;
 }
 
+// The variates use the kernel's own log / sincos (rsf_math.h, <= 4 ulp): the oracle's libm values differ in the last
+// bits, which matters only when an accept test sits within ~1e-15 of its threshold (tests: draws to 1e-12).
 __device__ __forceinline__ void normal_pair(const uint32_t w[4], double &z0, double &z1) {
   const double u1 = u53(w[0], w[1]), u2 = u53(w[2], w[3]);
-  const double r = sqrt(-2.0 * log(u1));
+#ifdef RSF_MATH_OCML
+  const double r = sqrt(-2.0 * ::log(u1));
   double s, c;
   sincos(6.283185307179586476925286766559 * u2, &s, &c);
+#else
+  const double r = sqrt(-2.0 * fm::log(u1));
+  double s, c;
+  fm::sincos2pi(u2, s, c);
+#endif
   z0 = r * c;
   z1 = r * s;
 }
 
-// Marsaglia & Tsang (2000), shape >= 1, log acceptance test only.
-__device__ __forceinline__ double gamma_draw(uint64_t seed, uint64_t chain, uint32_t iter, double shape) {
-  const double d = shape - 1.0 / 3.0;
-  const double c = 1.0 / sqrt(9.0 * d);
+__device__ __forceinline__ double rng_log(double x) {
+#ifdef RSF_MATH_OCML
+  return ::log(x);
+#else
+  return fm::log(x);
+#endif
+}
+
+// Marsaglia & Tsang (2000), shape >= 1, log acceptance test only.  d = shape - 1/3 and c = 1/sqrt(9 d) come from
+// the host (chain-independent).
+__device__ __forceinline__ double gamma_draw(uint64_t seed, uint64_t chain, uint32_t iter, double d, double c) {
   for (uint32_t j = 0; j < 64; ++j) {
     uint32_t w[4];
     double x, unused;
@@ -591,7 +621,7 @@ __device__ __forceinline__ double gamma_draw(uint64_t seed, uint64_t chain, uint
     v = v * v * v;
     draw_words(seed, chain, iter, SLOT_GAMMA + 2 * j + 1, w);
     const double u = u53(w[0], w[1]);
-    if (log(u) < 0.5 * x * x + d * (1.0 - v + log(v))) return d * v;
+    if (rng_log(u) < 0.5 * x * x + d * (1.0 - v + rng_log(v))) return d * v;
   }
   return d;
 }

@@ -259,6 +259,7 @@ struct McmcArgs {
   int64_t C, chain_offset, n_iters, iter_base;
   uint64_t seed;
   double n0, shape;
+  double gd, gc;  // Marsaglia-Tsang constants of Gamma(shape): d = shape - 1/3, c = 1/sqrt(9 d)
   double lo[RSF_MAX_PARAMS], hi[RSF_MAX_PARAMS];
   int32_t adapt_mode, adapt_interval;
   double *q, *ssq, *std2, *V;           // per-chain state
@@ -361,8 +362,10 @@ __global__ void __launch_bounds__(kMaxBlock, MODE == DOP853 ? 1 : RSF_MIN_BLOCKS
         rsf::draw_words(A.seed, gid, it, rsf::SLOT_U, w);
         u = rsf::u53(w[0], w[1]);
       }
-      const double logalpha = fmin(0.5 * (ssq - ssqn) / std2, 0.0);
-      accept = logalpha > log(u);  // NaN compares false => reject
+      // (replaying recorded variates follows the reference's arithmetic to the last bit: IEEE division, libm-grade log;
+      //  the sampler proper uses the kernel's own reciprocal and log — the same value to ~1 ulp)
+      const double logalpha = fmin(REPLAY ? 0.5 * (ssq - ssqn) / std2 : (0.5 * (ssq - ssqn)) * rsf::fm::rcp(std2), 0.0);
+      accept = logalpha > (REPLAY ? log(u) : rsf::rng_log(u));  // NaN compares false => reject
       ++n_eval;
       if (!isfinite(ssqn)) ++n_nonfinite;
       if (accept) {
@@ -375,8 +378,8 @@ __global__ void __launch_bounds__(kMaxBlock, MODE == DOP853 ? 1 : RSF_MIN_BLOCKS
     // ---- sigma^2 Gibbs update with the post-accept SSq, MCMC.py:158-160 ----
     if (valid) {
       const double bval = 0.5 * (A.n0 * std2 + ssq);
-      const double g = REPLAY ? A.g[row] : rsf::gamma_draw(A.seed, gid, it, A.shape);
-      std2 = bval / g;
+      const double g = REPLAY ? A.g[row] : rsf::gamma_draw(A.seed, gid, it, A.gd, A.gc);
+      std2 = REPLAY ? bval / g : bval * rsf::fm::rcp(g);
       if (A.tq) {
 #pragma unroll
         for (int p = 0; p < D; ++p) A.tq[row * D + p] = q[p];
@@ -537,7 +540,7 @@ __global__ void probe_draws_kernel(uint64_t seed, uint64_t chain, uint32_t iter,
     rsf::draw_words(seed, chain, iter, rsf::SLOT_U, w);
     out[0] = z[0]; out[1] = z[1]; out[2] = z[2];
     out[3] = rsf::u53(w[0], w[1]);
-    out[4] = rsf::gamma_draw(seed, chain, iter, shape);
+    out[4] = rsf::gamma_draw(seed, chain, iter, shape - 1.0 / 3.0, 1.0 / sqrt(9.0 * (shape - 1.0 / 3.0)));
   }
 }
 
@@ -651,6 +654,7 @@ Consts make_consts(const rsf_ctx *c, const double *data) {
   K.h = c->h; K.hh = 0.5 * c->h; K.h6 = c->h / 6.0;
   K.inv_dt = 1.0 / c->delta_t;
   K.cacc = K.h6 * K.inv_dt;
+  K.inv_vref = 1.0 / c->m.V_ref;
   K.t0 = c->m.t_start;
   K.dt = c->delta_t;
   K.vl = (const double *)c->vl.p;
@@ -759,6 +763,7 @@ int run_mcmc(rsf_ctx *c, int64_t n_iters, const double *z, const double *u, cons
   McmcArgs A{};
   A.C = C; A.chain_offset = c->mc.chain_offset; A.n_iters = n_iters; A.iter_base = c->iters_done;
   A.seed = c->mc.seed; A.n0 = c->mc.n0; A.shape = 0.5 * (c->mc.n0 + (double)c->nout);  // MCMC.py:158
+  A.gd = A.shape - 1.0 / 3.0; A.gc = 1.0 / std::sqrt(9.0 * A.gd);
   for (int p = 0; p < RSF_MAX_PARAMS; ++p) { A.lo[p] = c->mc.lo[p]; A.hi[p] = c->mc.hi[p]; }
   A.adapt_mode = c->mc.adapt_mode; A.adapt_interval = c->mc.adapt_interval > 0 ? c->mc.adapt_interval : 1;
   A.q = (double *)c->q.p; A.ssq = (double *)c->ssq.p; A.std2 = (double *)c->std2.p; A.V = (double *)c->V.p;

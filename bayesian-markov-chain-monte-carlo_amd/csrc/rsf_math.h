@@ -93,5 +93,36 @@ __device__ __forceinline__ double exp(double x) {
   return __builtin_amdgcn_ldexp(p, (int)k);  // v_cvt_i32_f64 saturates; v_ldexp_f64 over/underflows to inf/0
 }
 
+// sin and cos of 2*pi*u for u in [0, 1] (Box-Muller angle): quadrant k = rint(4u), r = u - k/4 exactly in
+// [-1/8, 1/8], theta = 2*pi*r in [-pi/4, pi/4] (two-piece 2*pi), Taylor to theta^15 / theta^16 (truncation < 5e-17).
+// ~35 instructions against ~150 for OCML's sincos with its full-range argument reduction.
+__device__ __forceinline__ void sincos2pi(double u, double &sn, double &cs) {
+  const double k = __builtin_rint(4.0 * u);
+  const double r = __builtin_fma(k, -0.25, u);
+  const double t = __builtin_fma(r, 0x1.1a62633145c07p-52, r * 0x1.921fb54442d18p+2);  // 2*pi = hi + lo
+  const double z = t * t;
+  double ps = -1.0 / 1307674368000.0;               // -1/15!
+  ps = __builtin_fma(ps, z, 1.0 / 6227020800.0);    //  1/13!
+  ps = __builtin_fma(ps, z, -1.0 / 39916800.0);     // -1/11!
+  ps = __builtin_fma(ps, z, 1.0 / 362880.0);        //  1/9!
+  ps = __builtin_fma(ps, z, -1.0 / 5040.0);         // -1/7!
+  ps = __builtin_fma(ps, z, 1.0 / 120.0);           //  1/5!
+  ps = __builtin_fma(ps, z, -1.0 / 6.0);            // -1/3!
+  const double s0 = __builtin_fma(t * z, ps, t);
+  double pc = 1.0 / 20922789888000.0;               //  1/16!
+  pc = __builtin_fma(pc, z, -1.0 / 87178291200.0);  // -1/14!
+  pc = __builtin_fma(pc, z, 1.0 / 479001600.0);     //  1/12!
+  pc = __builtin_fma(pc, z, -1.0 / 3628800.0);      // -1/10!
+  pc = __builtin_fma(pc, z, 1.0 / 40320.0);         //  1/8!
+  pc = __builtin_fma(pc, z, -1.0 / 720.0);          // -1/6!
+  pc = __builtin_fma(pc, z, 1.0 / 24.0);            //  1/4!
+  pc = __builtin_fma(pc, z, -0.5);
+  const double c0 = __builtin_fma(pc, z, 1.0);
+  const int q = (int)k & 3;                          // k in 0..4
+  const double a = (q & 1) ? c0 : s0, b = (q & 1) ? s0 : c0;
+  sn = (q & 2) ? -a : a;                             // q: 0 (s, c)  1 (c, -s)  2 (-s, -c)  3 (-c, s)
+  cs = ((q + 1) & 2) ? -b : b;
+}
+
 }  // namespace fm
 }  // namespace rsf
