@@ -1,6 +1,6 @@
 // probe_math.hip — test-only harness: evaluates the kernel's fp64 math helpers (csrc/rsf_math.h)
 // elementwise on the GPU so tests/test_gpu_math.py can compare them with NumPy.
-//   usage: probe_math <log|exp|rcp|rcp_seed> <in.f64> <out.f64>
+//   usage: probe_math <log|exp|rcp|rcp_seed|sin2pi|cos2pi> <in.f64> <out.f64>
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
@@ -18,16 +18,17 @@ __global__ void probe(int kind, int n, const double *in, double *out) {
     case 0: y = rsf::fm::log(x); break;
     case 1: y = rsf::fm::exp(x); break;
     case 2: y = rsf::fm::rcp(x); break;
-    default: y = __builtin_amdgcn_rcp(x); break;
+    case 3: y = __builtin_amdgcn_rcp(x); break;
+    default: { double sn, cs; rsf::fm::sincos2pi(x, sn, cs); y = kind == 4 ? sn : cs; } break;
   }
   out[i] = y;
 }
 
 int main(int argc, char **argv) {
   if (argc != 4) return 2;
-  const char *kinds[] = {"log", "exp", "rcp", "rcp_seed"};
+  const char *kinds[] = {"log", "exp", "rcp", "rcp_seed", "sin2pi", "cos2pi"};
   int kind = -1;
-  for (int k = 0; k < 4; ++k) if (!strcmp(argv[1], kinds[k])) kind = k;
+  for (int k = 0; k < 6; ++k) if (!strcmp(argv[1], kinds[k])) kind = k;
   if (kind < 0) return 2;
   FILE *f = fopen(argv[2], "rb");
   if (!f) return 3;

@@ -59,3 +59,24 @@ def test_rcp(probe):
     rel = np.abs(seed * x - 1.0).max()
     print(f"v_rcp_f64 seed max relative error: {rel:.3e}")
     assert rel < 1e-6
+
+
+def test_sincos2pi(probe):
+    """Box-Muller angle: sin/cos(2 pi u) for u = k * 2^-53 in (0, 1], absolute error at rounding level (the
+    reference value is formed in extended precision from the exactly reduced argument)."""
+    rng = np.random.default_rng(3)
+    u = (rng.integers(1, 2 ** 53, 300000, dtype=np.int64).astype(np.float64)) * 2.0 ** -53
+    u = np.concatenate([u, [2.0 ** -53, 0.125, 0.25, 0.375, 0.5, 0.625, 0.75, 0.875, 1.0, 1.0 - 2.0 ** -53, 0.25 + 2.0 ** -53]])
+    k = np.rint(4.0 * u)
+    r = (u - 0.25 * k).astype(np.longdouble)  # exact
+    th = r * (2 * np.longdouble(np.pi) + np.longdouble(1.2246467991473532e-16) * 2)
+    s0, c0 = np.sin(th), np.cos(th)
+    q = k.astype(np.int64) & 3
+    want_s = np.where(q == 0, s0, np.where(q == 1, c0, np.where(q == 2, -s0, -c0))).astype(np.float64)
+    want_c = np.where(q == 0, c0, np.where(q == 1, -s0, np.where(q == 2, -c0, s0))).astype(np.float64)
+    got_s, got_c = probe("sin2pi", u), probe("cos2pi", u)
+    assert np.abs(got_s - want_s).max() < 3e-16 and np.abs(got_c - want_c).max() < 3e-16
+    # relative accuracy also where the value is tiny (near the axes the reduced angle is exact)
+    big = np.abs(want_s) > 1e-300
+    assert (np.abs(got_s - want_s)[big] / np.abs(want_s)[big]).max() < 1e-15
+    assert np.abs(got_s ** 2 + got_c ** 2 - 1.0).max() < 1e-15
