@@ -130,11 +130,11 @@ __device__ __forceinline__ void rhs_tail(double w, double rx, double x, double v
 // so everything but one fma is ready before w is, and the damped d0 follows two instructions after w instead of
 // five.  (vb/x and vb w nearly cancel, but against vk V_l their rounding is ~3e-17 of the result.)
 template <bool DAMP>
-__device__ __forceinline__ void rhs_fast(double w, double rx, double x, double vl, const Lane &L,
-                                         const Consts &K, double &d0, double &d1, double &d2) {
+__device__ __forceinline__ void rhs_fast(double w, double x, double vl, double t1, const Lane &L, const Consts &K, double &d0,
+                                         double &d1, double &d2) {  // t1 = vk V_l - vb/x, formed by the caller (no w in it)
   d1 = __builtin_fma(-w, x, 1.0);
   d0 = __builtin_fma(-K.V_ref, w, vl);
-  double in = __builtin_fma(L.c3, w, __builtin_fma(-L.vb, rx, L.vk * vl));
+  double in = __builtin_fma(L.c3, w, t1);
   if (DAMP) {  // d0 -= k1/k' * (w in); then in again with the damped d0: in - vk (k1/k' w) in
     const double kw = L.k1k * w;
     d0 = __builtin_fma(-kw, in, d0);
@@ -171,6 +171,15 @@ __device__ __forceinline__ void eval_full(double ms, double x, const Lane &L, co
 // result and the loop branch: +3 % at cfg1.)
 enum Tier : int { TIGHT = 0, NARROW = 1, WIDE = 2 };
 
+// t1 of a stage.  TIGHT stages never form 1/x at the stage point: with 1/x' = (1/x)(1 + q), q = rho^2 - rho (eval_incr
+// hands q back in place of 1/x'), vb/x' = vbr0 + vbr0 q where vbr0 = vb/x at the step's start.
+template <int T>
+__device__ __forceinline__ double stage_t1(double vl, double rx_or_q, double vbr0, const Lane &L) {
+  if (T == TIGHT) return __builtin_fma(-vbr0, rx_or_q, __builtin_fma(L.vk, vl, -vbr0));
+  return __builtin_fma(-L.vb, rx_or_q, L.vk * vl);
+}
+
+
 #ifdef RSF_GUARD_F64
 struct Guard {
   double rho, dlt;
@@ -193,9 +202,9 @@ __device__ __forceinline__ void set_tier(Lane &L) {
   asm volatile("" : "+v"(L.c_l1p), "+v"(L.c_em1));  // opaque: stays a register value, not re-materialised per step
 }
 
-template <int T>
+template <int T, bool STAGE>
 __device__ __forceinline__ void eval_incr(double kf, double dms_dt, double R, double dth_dt, double x1, const Lane &L, double w0,
-                                          double rx0, double &w, double &rx, Guard &g) {
+                                          double rx0, double &w, double &rx, Guard &g) {  // TIGHT && STAGE: rx returns q (stage_t1)
   // dk = kf * dms_dt (kf: kia times the step fraction);  rho = R * dth_dt (R: step fraction / Dc / x, once per step)
   const double rho = dth_dt * R;
 #ifdef RSF_GUARD_F64
@@ -244,7 +253,8 @@ __device__ __forceinline__ void eval_incr(double kf, double dms_dt, double R, do
     rx = __builtin_fma(rx0, __builtin_fma(rho, rho, -rho), rx0);
     rx = __builtin_fma(rx, __builtin_fma(-x1, rx, 1.0), rx);
   } else {
-    rx = __builtin_fma(rx0, __builtin_fma(rho, rho, -rho), rx0);  // exact to rounding for |rho| < 2^-20; like w, resynced
+    const double q = __builtin_fma(rho, rho, -rho);
+    rx = STAGE ? q : __builtin_fma(rx0, q, rx0);  // exact to rounding for |rho| < 2^-20; like w, resynced
   }
 }
 
@@ -306,20 +316,21 @@ __device__ __forceinline__ double rk4_fast(State &s, double vl0, double vlm, dou
                                            const Consts &K, Guard &g) {
   double a0, a1, a2, b0, b1, b2, c0, c1, c2, e0, e1, e2, w, rx, xs;
   const double Rh = L.hhd * s.rx, Rf = Rh + Rh, R6 = L.h6d * s.rx;  // rho of a stage = its theta derivative times these
-  rhs_fast<DAMP>(s.w, s.rx, s.x, vl0, L, K, a0, a1, a2);
+  const double vbr0 = L.vb * s.rx;
+  rhs_fast<DAMP>(s.w, s.x, vl0, __builtin_fma(L.vk, vl0, -vbr0), L, K, a0, a1, a2);
   xs = __builtin_fma(L.hhd, a1, s.x);
-  eval_incr<T>(L.khh, a0, Rh, a1, xs, L, s.w, s.rx, w, rx, g);
-  rhs_fast<DAMP>(w, rx, xs, vlm, L, K, b0, b1, b2);
+  eval_incr<T, true>(L.khh, a0, Rh, a1, xs, L, s.w, s.rx, w, rx, g);
+  rhs_fast<DAMP>(w, xs, vlm, stage_t1<T>(vlm, rx, vbr0, L), L, K, b0, b1, b2);
   xs = __builtin_fma(L.hhd, b1, s.x);
-  eval_incr<T>(L.khh, b0, Rh, b1, xs, L, s.w, s.rx, w, rx, g);
-  rhs_fast<DAMP>(w, rx, xs, vlm, L, K, c0, c1, c2);
+  eval_incr<T, true>(L.khh, b0, Rh, b1, xs, L, s.w, s.rx, w, rx, g);
+  rhs_fast<DAMP>(w, xs, vlm, stage_t1<T>(vlm, rx, vbr0, L), L, K, c0, c1, c2);
   xs = __builtin_fma(L.hd, c1, s.x);
-  eval_incr<T>(L.kh, c0, Rf, c1, xs, L, s.w, s.rx, w, rx, g);
-  rhs_fast<DAMP>(w, rx, xs, vl1, L, K, e0, e1, e2);
+  eval_incr<T, true>(L.kh, c0, Rf, c1, xs, L, s.w, s.rx, w, rx, g);
+  rhs_fast<DAMP>(w, xs, vl1, stage_t1<T>(vl1, rx, vbr0, L), L, K, e0, e1, e2);
   const double t0 = a0 + 2.0 * b0 + 2.0 * c0 + e0;
   const double t1 = a1 + 2.0 * b1 + 2.0 * c1 + e1;
   const double x1 = __builtin_fma(L.h6d, t1, s.x);
-  eval_incr<T>(L.kh6, t0, R6, t1, x1, L, s.w, s.rx, w, rx, g);
+  eval_incr<T, false>(L.kh6, t0, R6, t1, x1, L, s.w, s.rx, w, rx, g);
   s.ms = __builtin_fma(K.h6, t0, s.ms);
   s.x = x1;
   s.w = w;
