@@ -167,14 +167,18 @@ class MCMC:
         return qparams[:, self.nburn:]
 
     def sample_batched(self, n_chains, seed=0, q0=None, jitter=None, n_iters=None, iters_per_launch=None,
-                       adapt_mode=None, mem="device", device=-1, chain_offset=0, keep="post_burn"):
+                       adapt_mode=None, mem="device", device=-1, chain_offset=0, keep="post_burn", thin=1):
         """Throughput path (additive): n_chains independent chains, Philox variates on device.
 
         q0: (C,) / (C, d) start points; default qstart for every chain, optionally jittered
         uniformly in `jitter=(lo, hi)` with a NumPy generator seeded by `seed` and keyed by
-        global chain id.  Returns a PosteriorPool of the post-burn-in draws."""
+        global chain id.  Returns a PosteriorPool of the post-burn-in draws; `thin=k` keeps every k-th kept draw
+        (the pool of a long multi-GPU run need not hold, or all-gather, every iteration: SURVEY §8e)."""
         from .engine import Engine
 
+        if int(thin) < 1:
+            raise ValueError("thin must be >= 1")
+        thin = int(thin)
         n_iters = self.nsamples if n_iters is None else n_iters
         nburn = int(n_iters / 2) if keep == "post_burn" else 0
         gids = chain_offset + np.arange(n_chains)
@@ -200,7 +204,7 @@ class MCMC:
             eng.sync()
             stats = eng.stats()
             cat = (lambda xs: np.concatenate([np.asarray(x.cpu() if hasattr(x, "cpu") else x) for x in xs], axis=0))
-            samples, std2 = cat(kept_q), cat(kept_s)
+            samples, std2 = cat(kept_q)[::thin], cat(kept_s)[::thin]
         finally:
             eng.close()
         rate = stats["accepted"] / max(1, n_iters * n_chains)

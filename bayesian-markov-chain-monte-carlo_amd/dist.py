@@ -101,7 +101,7 @@ def pool_to_chain_major(pool):
 
 
 def run_sharded(engine_factory, model, substeps, data, q0_global, lo, hi, n_iters, nburn, seed=0, mcmc_kwargs=None,
-                device=None):
+                device=None, thin=1):
     """Each rank samples its shard, then the kept draws are all-gathered.
 
     engine_factory() → Engine for this rank (the product passes `lambda: Engine(mem="device")`;
@@ -121,7 +121,7 @@ def run_sharded(engine_factory, model, substeps, data, q0_global, lo, hi, n_iter
         tq, _, _ = eng.mcmc_run(n_iters, traces=("q",))
         eng.sync()
         stats = eng.stats()
-        kept = tq[max(nburn - 1, 0):]
+        kept = tq[max(nburn - 1, 0):][::thin]  # thin=k: every k-th kept draw goes into the pool
         if not isinstance(kept, torch.Tensor):
             kept = torch.from_numpy(np.ascontiguousarray(kept))
         if device is not None:

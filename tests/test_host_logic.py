@@ -159,3 +159,8 @@ def test_sample_batched_host_logic(pkg, model, golden, monkeypatch):
     assert one.pooled().shape == (1, 88) and 0 < one.accept_rate <= 1
     jit = mc.sample_batched(8, seed=4, mem="host", jitter=(500.0, 1500.0))
     assert not np.array_equal(jit.samples, one.samples)
+    thinned = mc.sample_batched(8, seed=4, mem="host", iters_per_launch=7, thin=3)
+    np.testing.assert_array_equal(thinned.samples, one.samples[::3])
+    np.testing.assert_array_equal(thinned.std2, one.std2[::3])
+    with pytest.raises(ValueError):
+        mc.sample_batched(8, seed=4, mem="host", thin=0)
