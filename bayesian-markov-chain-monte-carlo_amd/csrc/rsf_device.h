@@ -275,10 +275,10 @@ __device__ __forceinline__ bool guard_ok(const Guard &g) {  // NaN passes throug
 // transcendental at all; stages 2-4 and the step's end point are reached by eval_incr from the
 // step's start point.  Straight-line code on purpose: with one wave per SIMD (cfg1) every
 // instruction, nop and branch costs a full ~5-cycle issue slot (tools/microbench_fp64.hip).
-// The largest relative increment of the step is checked ONCE; if a lane exceeded 2^-9 (stiff
-// small-Dc proposals) the step is redone from the saved start point with full evaluations
-// (rk4_cold).  Every RSF_RESYNC steps (w, 1/x) are recomputed in full so rounding in the
-// incremental products cannot accumulate (1/th is self-correcting through its Newton steps).
+// The largest increments of a PAIR of steps are checked once (integrate_pairs); if a lane left the tier's
+// guard region (stiff small-Dc proposals) the pair is redone from the saved start point with full
+// evaluations (rk4_cold).  Every RSF_RESYNC steps (w, 1/x) are recomputed in full so rounding in the
+// incremental products cannot accumulate.
 // ---------------------------------------------------------------------------------------------
 #ifndef RSF_RESYNC
 #define RSF_RESYNC 128
