@@ -43,11 +43,13 @@ __device__ __forceinline__ void select_group(Consts &K) {
 }
 
 // Per-lane proposal constants, hoisted out of the time loop.  The integrator works on the rescaled state
-//   ms = mu / k'      (k' = 1e-2*10/Dc, RateStateModel.py:324)      x = theta / Dc
+//   ms = mu / k'      (k' = 1e-2*10/Dc, RateStateModel.py:324)      x = V_ref theta / Dc
 // — a linear change of variables, so RK4 produces the same trajectory to rounding — because two
-// multiplications then drop out of every RHS evaluation: d(ms)/dt = V_l - v and d(theta)/dt = 1 - w x.
+// multiplications then drop out of every RHS evaluation: d(ms)/dt = V_l - v and d(theta)/dt = 1 - w x
+// (w = v/V_ref, so w x = v theta/Dc, and log(V_ref theta/Dc) = log x).
 struct Lane {
   double inv_dc;  // 1/Dc
+  double vdc;     // V_ref/Dc      : dx/dt = vdc * d1
   double kprime;  // k'
   double kia;     // k'/a          : d(mu)/a = kia * d(ms)
   double khh, kh, kh6;  // kia*(h/2), kia*h, kia*(h/6): d(mu)/a of a stage / step straight from the ms derivative
@@ -83,15 +85,16 @@ __device__ __forceinline__ Lane make_lane(double dc, double a, double b, const C
   L.kh6 = L.kia * K.h6;
   L.k1k = (K.k1 * dc) * (1.0 / (1e-2 * 10));  // k1/k'
   L.via = K.V_ref * inv_a;
-  L.bdc = b * L.inv_dc;
+  L.vdc = K.V_ref * L.inv_dc;
+  L.bdc = b * L.vdc;               // b/theta = (b V_ref/Dc) / x
   L.vk = L.via * L.kprime;
   L.vb = L.via * L.bdc;
   L.c3 = __builtin_fma(-L.vk, K.V_ref, L.vb);
   L.boa = b * inv_a;
   L.tc = -K.mu_ref * inv_a;
-  L.hhd = K.hh * L.inv_dc;
-  L.hd = K.h * L.inv_dc;
-  L.h6d = K.h6 * L.inv_dc;
+  L.hhd = K.hh * L.vdc;
+  L.hd = K.h * L.vdc;
+  L.h6d = K.h6 * L.vdc;
   set_tier<2>(L);
   return L;
 }
@@ -102,8 +105,8 @@ __device__ __forceinline__ Lane make_lane(double dc, double a, double b, const C
 // the slip rate appears only as w = v/V_ref = exp((mu-mu_ref)/a - (b/a) log(V_ref*theta/Dc)).
 // ---------------------------------------------------------------------------------------------
 
-// Integration state of one lane: ms = mu/k', x = theta/Dc, V, and the transcendental parts of the RHS at
-// that point:  w = v/V_ref = exp(mu/a - mu_ref/a - (b/a) log(V_ref x)),   rx = 1/x.
+// Integration state of one lane: ms = mu/k', x = V_ref theta/Dc, V, and the transcendental parts of the RHS at
+// that point:  w = v/V_ref = exp(mu/a - mu_ref/a - (b/a) log x),   rx = 1/x.
 struct State {
   double ms, x, V;
   double w, rx;
@@ -146,10 +149,10 @@ __device__ __forceinline__ void rhs_fast(double w, double x, double vl, double t
 // (w, 1/x) by full evaluation
 __device__ __forceinline__ void eval_full(double ms, double x, const Lane &L, const Consts &K, double &w, double &rx) {
 #ifdef RSF_MATH_OCML
-  w = ::exp(__builtin_fma(-L.boa, ::log(x * K.V_ref), __builtin_fma(ms, L.kia, L.tc)));
+  w = ::exp(__builtin_fma(-L.boa, ::log(x), __builtin_fma(ms, L.kia, L.tc)));
   rx = 1.0 / x;
 #else
-  w = fm::exp(__builtin_fma(-L.boa, fm::log(x * K.V_ref), __builtin_fma(ms, L.kia, L.tc)));
+  w = fm::exp(__builtin_fma(-L.boa, fm::log(x), __builtin_fma(ms, L.kia, L.tc)));
   rx = fm::rcp(x);
 #endif
 }
@@ -296,7 +299,7 @@ __device__ __forceinline__ double rk4_cold(State &s, double vl0, double vlm, dou
     const double c = st == 0 ? 0.0 : (st == 3 ? K.h : K.hh);
     const double wgt = (st == 0 || st == 3) ? 1.0 : 2.0;
     const double vl = st == 0 ? vl0 : (st == 3 ? vl1 : vlm);
-    const double x1 = __builtin_fma(c * L.inv_dc, k1, s.x);
+    const double x1 = __builtin_fma(c * L.vdc, k1, s.x);
     double w, rx, d0, d1, d2;
     eval_full(__builtin_fma(c, k0, s.ms), x1, L, K, w, rx);
     rhs_tail<DAMP>(w, rx, x1, vl, L, K, d0, d1, d2);
@@ -362,7 +365,7 @@ __device__ __forceinline__ void rk4_step(State &s, bool resync, double vl0, doub
 __device__ __forceinline__ State initial_state(double dc, const Lane &L, const Consts &K) {
   State s;
   s.ms = (K.mu0 * dc) * (1.0 / (1e-2 * 10));  // mu(0)/k' = mu_t_zero/k', RateStateModel.py:367-377
-  s.x = (dc * K.inv_vref) * L.inv_dc;         // theta(0)/Dc = (Dc/V_ref)/Dc
+  s.x = K.V_ref * ((dc * K.inv_vref) * L.inv_dc);  // V_ref theta(0)/Dc with theta(0) = Dc/V_ref: 1 to rounding
   s.V = K.V_ref;
   eval_full(s.ms, s.x, L, K, s.w, s.rx);
   return s;

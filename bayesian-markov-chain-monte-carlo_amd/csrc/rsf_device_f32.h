@@ -8,7 +8,7 @@
 // 2^x, v_rcp_f32; ~1 ulp), so every RK4 stage is evaluated in full — no incremental series — and
 // the constants are pre-scaled for base 2.  The acceleration sample is formed from the step's
 // velocity INCREMENT, not from the difference of two velocities near V_ref, which would lose
-// ~4 digits in float32.  Same rescaled state as the float64 path: ms = mu/k', x = theta/Dc.
+// ~4 digits in float32.  Same rescaled state as the float64 path: ms = mu/k', x = V_ref theta/Dc.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -20,7 +20,7 @@ namespace f32 {
 
 struct Lane32 {
   float kia2;    // (k'/a) log2(e)
-  float tc2;     // -(mu_ref/a) log2(e) - (b/a) log2(V_ref)
+  float tc2;     // -(mu_ref/a) log2(e)
   float boa;     // b/a
   float kprime, k1k, via, bdc;
   float hh, h, h6, hhd, hd, h6d, vref;
@@ -31,14 +31,15 @@ __device__ __forceinline__ Lane32 make_lane32(double dc, double a, double b, con
   const double inv_a = 1.0 / a, inv_dc = 1.0 / dc, kprime = (1e-2 * 10) / dc;
   Lane32 L;
   L.kia2 = (float)(kprime * inv_a * log2e);
-  L.tc2 = (float)(-K.mu_ref * inv_a * log2e - b * inv_a * ::log2(K.V_ref));
+  L.tc2 = (float)(-K.mu_ref * inv_a * log2e);
   L.boa = (float)(b * inv_a);
   L.kprime = (float)kprime;
   L.k1k = (float)(K.k1 / kprime);
   L.via = (float)(K.V_ref * inv_a);
-  L.bdc = (float)(b * inv_dc);
+  L.bdc = (float)(b * K.V_ref * inv_dc);
   L.hh = (float)K.hh; L.h = (float)K.h; L.h6 = (float)K.h6;
-  L.hhd = (float)(K.hh * inv_dc); L.hd = (float)(K.h * inv_dc); L.h6d = (float)(K.h6 * inv_dc);
+  const double vdc = K.V_ref * inv_dc;  // dx/dt = (V_ref/Dc) (1 - w x)
+  L.hhd = (float)(K.hh * vdc); L.hd = (float)(K.h * vdc); L.h6d = (float)(K.h6 * vdc);
   L.vref = (float)K.V_ref;
   return L;
 }
@@ -108,7 +109,7 @@ template <bool DAMP, bool WANT_SSQ, bool WANT_ACC>
 __device__ __forceinline__ double solve32(float *lds, const Consts &K, bool resident, bool active, double dc, double a,
                                           double b, double *acc_out, int64_t stride) {
   const Lane32 L = make_lane32(dc, a, b, K);
-  float ms = (float)(K.mu0 / ((1e-2 * 10) / dc)), x = (float)(1.0 / K.V_ref);
+  float ms = (float)(K.mu0 / ((1e-2 * 10) / dc)), x = 1.0f;  // x = V_ref theta(0)/Dc, theta(0) = Dc/V_ref
   double ssq = 0.0;
   if (WANT_SSQ && active) {
     const double d0 = (double)(float)K.data[0];

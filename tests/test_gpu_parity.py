@@ -70,6 +70,42 @@ def test_forward_trajectory_and_ssq(gpu_engine, cpu_engine, oracle_mod, n, subst
         np.testing.assert_array_equal(a2, ag)
 
 
+@pytest.mark.parametrize("precision,integrator,rtol", [("float64", "rk4", RTOL), ("float64", "dop853", RTOL), ("float32", "rk4", None)])
+def test_forward_with_non_default_model_constants(gpu_engine, cpu_engine, oracle_mod, precision, integrator, rtol):
+    """Every model attribute of RateStateModel is user-settable (RateStateModel.py:167-184); nothing in the kernels may
+    assume the defaults (V_ref = 1, mu_t_zero = mu_ref, t_start = 0 ...).  fp32 is checked against the fp64 GPU solve."""
+    m = _models(oracle_mod, 400, 2 if integrator == "rk4" else 1, True, t1=37.0)
+    m.t_start, m.delta_t = 1.5, (37.0 - 1.5) / 400
+    m.V_ref, m.mu_ref, m.mu_t_zero, m.k1, m.a, m.b = 1.7, 0.55, 0.58, 3.0e-7, 0.012, 0.0155
+    m.integrator = integrator
+    rng = np.random.default_rng(5)
+    C = 130
+    dc = rng.uniform(300.0, 6000.0, C)
+    a = rng.uniform(0.009, 0.015, C)
+    b = a + rng.uniform(-0.003, 0.006, C)
+    for e in (gpu_engine, cpu_engine):
+        assert e.set_model(m, m.substeps) == m.nout
+    data = synthetic_data(cpu_engine)
+    for kw in (dict(), dict(a=a, b=b)):
+        sc, ac = cpu_engine.forward(dc, data=data, want_ssq=True, want_acc=True, **kw)
+        if precision == "float64":
+            sg, ag = gpu_engine.forward(dc, data=data, want_ssq=True, want_acc=True, **kw)
+            assert _traj_err(ag, ac) < rtol
+            np.testing.assert_allclose(sg, sc, rtol=rtol)
+        else:
+            m.precision = "float32"
+            gpu_engine.set_model(m, m.substeps)
+            sg, ag = gpu_engine.forward(dc, data=data, want_ssq=True, want_acc=True, **kw)
+            m.precision = "float64"
+            assert _traj_err(ag, ac) < 2e-3  # float32 solve: DESIGN "float32 solve" tolerance band
+            np.testing.assert_allclose(sg, sc, rtol=5e-3)
+    # and the sampler on top of it (initial covariance + a few iterations) for the float64 modes
+    if precision == "float64":
+        q0 = np.full((C, 1), 1500.0)
+        tg, tc = _run_pair(gpu_engine, cpu_engine, 12, C, q0, data, [0.0], [1e4], seed=9, prior_len=3)
+        _assert_chains_match(tg, tc, min_same=0.98)
+
+
 def test_forward_edge_sizes(gpu_engine, cpu_engine, oracle_mod):
     m = _models(oracle_mod, 500)
     for e in (gpu_engine, cpu_engine):

@@ -92,6 +92,23 @@ def test_c_oracle_matches_numpy_twin(cpu_engine, oracle_mod):
     np.testing.assert_allclose(ssq, oracle_mod.ssq_rk4(m, dc, data, a, b), rtol=1e-10)
 
 
+def test_c_oracle_with_non_default_model_constants(cpu_engine, oracle_mod):
+    """V_ref != 1, mu_t_zero != mu_ref, t_start != 0, other k1/a/b: the C restatement against the literal NumPy twin
+    (RK4) and against SciPy's dop853 driven exactly like the reference (DOP853 mode)."""
+    m = oracle_mod.ModelSpec(400, 0.0, 37.0, 2)
+    m.t_start, m.delta_t = 1.5, (37.0 - 1.5) / 400
+    m.V_ref, m.mu_ref, m.mu_t_zero, m.k1, m.a, m.b = 1.7, 0.55, 0.58, 3.0e-7, 0.012, 0.0155
+    assert cpu_engine.set_model(m, 2) == m.nout
+    dc = np.array([300.0, 1000.0, 6000.0])
+    _, acc = cpu_engine.forward(dc)
+    assert _traj_err(acc, oracle_mod.forward_rk4(m, dc)) < 1e-11
+    m.integrator, m.substeps = "dop853", 1
+    cpu_engine.set_model(m, 1)
+    _, acc = cpu_engine.forward(dc)
+    ref = np.stack([oracle_mod.forward_dop853(m, d) for d in dc], axis=1)
+    assert _traj_err(acc, ref) < 1e-10
+
+
 def test_ssq_grid_against_reference(cpu_engine, oracle_mod, golden):
     g = golden.npz("ssq")
     big = g["qgrid"] >= 700.0  # the S = 1 ladder value (7.4e-5) is for Dc >~ 100-1000; smaller Dc is stiffer
