@@ -47,7 +47,7 @@ class RateStateModel:
 
     # ---- engine plumbing ----------------------------------------------------------------
     def _model_key(self):
-        return (self.a, self.b, self.mu_ref, self.V_ref, self.k1, self.t_start, self.t_final, self.num_tsteps,
+        return (self.a, self.b, self.mu_ref, self.V_ref, self.k1, self.t_start, self.t_final, self.num_tsteps, self.delta_t,
                 self.mu_t_zero, bool(self.RadiationDamping), int(self.substeps), self.precision, self.integrator)
 
     def engine(self):

@@ -32,6 +32,15 @@ def _model_struct(model, substeps):
             raise ValueError("the dop853 integrator is float64 only")
         m.flags |= _abi.FLAG_DOP853
     m.nsteps = int(model.num_tsteps)
+    # the reference steps by its `delta_t` attribute and counts floor((t_final - t_start)/delta_t) samples
+    # (RateStateModel.py:176,358); the C ABI derives delta_t from (t_start, t_final, num_tsteps), so a model whose
+    # delta_t was edited out of step with them would silently integrate something else here: refuse it
+    dt_attr = getattr(model, "delta_t", None)
+    if dt_attr is not None:
+        dt = (float(model.t_final) - float(model.t_start)) / m.nsteps
+        if abs(float(dt_attr) - dt) > 1e-12 * abs(dt):
+            raise ValueError(f"model.delta_t = {dt_attr!r} is not (t_final - t_start)/num_tsteps = {dt!r}; "
+                             "set t_start, t_final, num_tsteps and delta_t consistently")
     m.substeps = int(substeps)
     m.t_start, m.t_final = float(model.t_start), float(model.t_final)
     m.mu_ref, m.V_ref, m.k1 = float(model.mu_ref), float(model.V_ref), float(model.k1)

@@ -123,6 +123,19 @@ def test_header_compiles_as_c_and_runs_against_the_oracle(oracle_mod, tmp_path):
     assert 800 < float(mean) < 1200 and float(std2) > 0 and int(ev) == 640 and int(done) == 10 and int(nonfinite) == 0
 
 
+def test_inconsistent_delta_t_is_refused(pkg, oracle_lib, oracle_mod):
+    """The reference integrates with its delta_t attribute; a model whose delta_t no longer matches
+    (t_final - t_start)/num_tsteps must not be integrated with a silently different step."""
+    m = oracle_mod.ModelSpec(500)
+    with pkg.Engine(lib=oracle_lib) as e:
+        assert e.set_model(m, 1) == 500
+        m.t_final = 40.0  # delta_t still 0.1
+        with pytest.raises(ValueError, match="delta_t"):
+            e.set_model(m, 1)
+        m.delta_t = 40.0 / 500
+        assert e.set_model(m, 1) == m.nout
+
+
 def test_pool_collectives_call_order_and_single_rank(pkg, oracle_lib):
     """rsf_comm_* / rsf_pool_allgather / rsf_pool_allreduce_sum on the checker: world = 1 is the identity, anything
     before rsf_comm_init is a call-order error, and the single-process checker refuses world > 1."""

@@ -211,23 +211,30 @@ def test_mcmc_continuation_equals_single_launch(gpu_engine, oracle_mod):
         np.testing.assert_array_equal(np.concatenate([p[k] for p in parts]), one[k])
 
 
-def test_host_caller_drain_pipeline_equals_single_launch(pkg, oracle_mod, monkeypatch):
+@pytest.mark.parametrize("d", [1, 3])
+def test_host_caller_drain_pipeline_equals_single_launch(pkg, oracle_mod, monkeypatch, d):
     """RSF_MEM_HOST runs longer than the drain budget are cut into launches whose trace rows are copied out on a
     second stream while the next launch computes; the rows must be those of the one-launch run, also when only some
     of the trace arrays are requested."""
     m = _models(oracle_mod, 500)
-    q0 = np.full((200, 1), 900.0)
+    C = 200
+    q0 = np.tile(np.array([900.0, 0.011, 0.014][:d]), (C, 1))
+    lo, hi = [0.0, 0.005, 0.005][:d], [1e4, 0.02, 0.03][:d]
+    V0 = np.tile(np.diag(np.array([20.0 ** 2, 1e-4 ** 2, 1e-4 ** 2][:d])), (C, 1, 1))
+    adapt = dict(prior_len=2, adapt_mode="reference_dict", adapt_interval=5) if d == 1 else dict(adapt_mode="am", adapt_interval=5)
 
     def run(want):
         with pkg.Engine(mem="host") as e:
             e.set_model(m, 1)
             data = synthetic_data(e)
-            e.mcmc_init(q0, data, [0.0], [1e4], seed=5, prior_len=2, adapt_mode="reference_dict", adapt_interval=5)
+            e.mcmc_init(q0, data, lo, hi, seed=5, **adapt)
+            e.set_state(V=V0)
             out = e.mcmc_run(23, traces=want)
             return out, e.get_state(), e.stats()
 
     one, st1, s1 = run(True)
-    monkeypatch.setenv("RSF_DRAIN_BYTES", str(200 * 17 * 3 + 5))  # 3 iterations per launch, last launch ragged
+    assert 0 < s1["accepted"] < 23 * C  # the chains move: a row written to the wrong place would show
+    monkeypatch.setenv("RSF_DRAIN_BYTES", str(C * (8 * d + 9) * 3 + 5))  # 3 iterations per launch, last launch ragged
     cut, st2, s2 = run(True)
     for k in range(3):
         np.testing.assert_array_equal(cut[k], one[k])
