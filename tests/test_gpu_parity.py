@@ -123,6 +123,22 @@ def test_forward_edge_sizes(gpu_engine, cpu_engine, oracle_mod):
     assert (np.isfinite(sg) == np.isfinite(sc)).all() and not np.isfinite(sg[0])
 
 
+@pytest.mark.parametrize("integrator", ["rk4", "dop853"])
+def test_forward_smallest_series(gpu_engine, cpu_engine, oracle_mod, integrator):
+    """nout = 2, 3, 4, 5: only the odd last step / one pair / pair + odd step / two pairs of the hot loop run."""
+    for n in (2, 3, 4, 5):
+        m = _models(oracle_mod, n, 1, True, t1=0.1 * n)
+        m.integrator = integrator
+        for e in (gpu_engine, cpu_engine):
+            assert e.set_model(m, 1) == n
+        dc = np.array([400.0, 1000.0, 2500.0])
+        data = np.linspace(0.001, 0.002, n)
+        sg, ag = gpu_engine.forward(dc, data=data, want_ssq=True, want_acc=True)
+        sc, ac = cpu_engine.forward(dc, data=data, want_ssq=True, want_acc=True)
+        np.testing.assert_allclose(ag, ac, rtol=RTOL, atol=1e-18)
+        np.testing.assert_allclose(sg, sc, rtol=RTOL)
+
+
 def test_forward_against_reference_golden(gpu_engine, oracle_mod, golden):
     """Tier 2: the GPU trajectory converges to the reference's dop853 output at 16x per halving."""
     g = golden.npz("forward")
