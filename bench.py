@@ -17,7 +17,8 @@ Also printed in the same JSON line:
   roofline      HBM view the metric names (algorithmic 16 B per chain-proposal) + the fp64-VALU
                 view that actually bounds this kernel (152 nominal flops per RK4 step);
   cpu_baseline  the CPU restatement (oracle/, OpenMP over chains) timed on this host's cores on a
-                bounded sample of the same workload (rank 0, N = 1 only).
+                bounded sample of the same workload (rank 0, N = 1 only);
+  reference_scheme  the same workload integrated with the reference's own DOP853 scheme (short side run, N = 1 only).
 """
 import argparse
 import ctypes
@@ -99,6 +100,32 @@ def cpu_baseline(model, data, target_s=12.0):
     return dict(value=chains * iters * nsteps / wall, unit="ODE-steps*chains/s", cores=cores, kind="port", single_thread_value=one_core,
                 sample=f"{chains} chains x {iters} proposals x nsteps {nsteps} ({nout - 1} RK4 steps each), "
                        f"oracle/librsf_oracle.so with OpenMP over chains, {wall:.1f} s")
+
+
+def reference_scheme_rate(model, data, C, nsteps, proposals=5):
+    """The same workload with the reference's OWN integration scheme (RateStateModel.integrator = "dop853": Hairer's
+    DOP853 driven like scipy.integrate.ode does, the mode whose numbers are identical to the reference's) — a short
+    side measurement next to the headline RK4 figure, outside its timed region."""
+    import torch
+
+    import bayesian_markov_chain_monte_carlo_amd as pkg
+
+    model.integrator = "dop853"
+    try:
+        with pkg.Engine(mem="device") as e:
+            e.set_model(model, 1)
+            q0 = torch.full((C, 1), 1000.0, dtype=torch.float64, device="cuda")
+            e.mcmc_init(q0, data, [0.0], [1.0e4], seed=2025, prior_len=3, adapt_mode="none")
+            e.mcmc_run(proposals, traces=False)
+            e.sync()
+            t0 = time.perf_counter()
+            e.mcmc_run(proposals, traces=False)
+            e.sync()
+            dt = time.perf_counter() - t0
+    finally:
+        model.integrator = "rk4"
+    return {"integrator": "dop853 (rtol 1e-6, atol 1e-10, as the reference)", "value": C * proposals * nsteps / dt,
+            "unit": "ODE-steps*chains/s", "sample": f"{C} chains x {proposals} proposals x nsteps {nsteps}"}
 
 
 def abi_pool_allgather(eng, local, expected_pool, rdist, timeout_s=90.0):
@@ -245,6 +272,7 @@ def main():
         if abi_pool is not None:
             out["pool_allgather_c_abi"] = abi_pool
         if world == 1 and not args.no_cpu_baseline:
+            out["reference_scheme"] = reference_scheme_rate(model, data, C, nsteps)
             out["cpu_baseline"] = cpu_baseline(model, data)
         print(json.dumps(out), flush=True)
     if abi_pool is not None and abi_pool.get("status") == "timeout":
