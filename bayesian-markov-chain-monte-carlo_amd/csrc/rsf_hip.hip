@@ -22,6 +22,8 @@
 #include <cstdlib>
 #include <algorithm>
 #include <cstring>
+#include <functional>
+#include <mutex>
 #include <vector>
 
 #include "../../include/rsf_abi.h"
@@ -808,11 +810,7 @@ struct Rccl {
   decltype(&ncclGetErrorString) error_string = nullptr;
 };
 
-const Rccl *rccl() {
-  static Rccl r;
-  static bool tried = false;
-  if (tried) return r.h ? &r : nullptr;
-  tried = true;
+void bind_rccl(Rccl &r) {
   const char *env = std::getenv("RSF_RCCL_LIB");
   const char *names[] = {"librccl.so", "librccl.so.1"};
   if (env && *env) r.h = dlopen(env, RTLD_NOW | RTLD_GLOBAL);
@@ -824,18 +822,21 @@ const Rccl *rccl() {
   }
   for (const char *n : names) if (!r.h) r.h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
   if (!r.h) r.h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
-  if (!r.h) return nullptr;
+  if (!r.h) return;
   r.get_unique_id = (decltype(r.get_unique_id))dlsym(r.h, "ncclGetUniqueId");
   r.comm_init_rank = (decltype(r.comm_init_rank))dlsym(r.h, "ncclCommInitRank");
   r.comm_destroy = (decltype(r.comm_destroy))dlsym(r.h, "ncclCommDestroy");
   r.all_gather = (decltype(r.all_gather))dlsym(r.h, "ncclAllGather");
   r.all_reduce = (decltype(r.all_reduce))dlsym(r.h, "ncclAllReduce");
   r.error_string = (decltype(r.error_string))dlsym(r.h, "ncclGetErrorString");
-  if (!r.get_unique_id || !r.comm_init_rank || !r.comm_destroy || !r.all_gather || !r.all_reduce || !r.error_string) {
-    r.h = nullptr;
-    return nullptr;
-  }
-  return &r;
+  if (!r.get_unique_id || !r.comm_init_rank || !r.comm_destroy || !r.all_gather || !r.all_reduce || !r.error_string) r.h = nullptr;
+}
+
+const Rccl *rccl() {  // bound once, whichever thread asks first
+  static Rccl r;
+  static std::once_flag once;
+  std::call_once(once, bind_rccl, std::ref(r));
+  return r.h ? &r : nullptr;
 }
 
 #define RCCL_TRY(R, expr)                                                                          \
