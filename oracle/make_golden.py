@@ -71,6 +71,29 @@ def forward_vectors():
         json.dump(dict(source="RateStateModel.evaluate()[1], RateStateModel.py:188-395", cases=cases), f, indent=1)
 
 
+def nondefault_vectors():
+    """G1b: the same, with every model attribute moved off its default (V_ref != 1, mu_t_zero != mu_ref, t_start != 0,
+    other k1 / a / b) — pins how the restatements treat those attributes against the reference itself."""
+    attrs = dict(V_ref=1.7, mu_ref=0.55, mu_t_zero=0.58, k1=3.0e-7, a=0.012, b=0.0155)
+    cases, series = [], {}
+    for damping in (True, False):
+        for dc in (300.0, 1000.0, 6000.0):
+            m = RateStateModel(number_time_steps=400, start_time=1.5, end_time=37.0)
+            for k, v in attrs.items():
+                setattr(m, k, v)
+            m.RadiationDamping = damping
+            m.Dc = dc
+            np.random.seed(0)
+            t, acc, _ = m.evaluate()
+            tag = f"dc{dc:g}" + ("" if damping else "_nodamp")
+            series[tag] = acc
+            cases.append(dict(tag=tag, dc=dc, damping=damping, nout=len(acc), t_first=float(t[0]), t_last=float(t[-1])))
+    np.savez_compressed(os.path.join(OUT, "forward_nondefault.npz"), **series)
+    with open(os.path.join(OUT, "forward_nondefault.json"), "w") as f:
+        json.dump(dict(source="RateStateModel.evaluate()[1] with non-default attributes, RateStateModel.py:167-395",
+                       number_time_steps=400, start_time=1.5, end_time=37.0, attrs=attrs, cases=cases), f, indent=1)
+
+
 # ---------------------------------------------------------------------------------------------
 def make_data(n, dc_true, seed):
     m = RateStateModel(number_time_steps=n)
@@ -220,8 +243,12 @@ def config1_run():
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--long", action="store_true")
+    ap.add_argument("--only-nondefault", action="store_true", help="write only forward_nondefault.* (added later)")
     args = ap.parse_args()
     os.makedirs(OUT, exist_ok=True)
+    nondefault_vectors()
+    if args.only_nondefault:
+        sys.exit(0)
     forward_vectors()
     ssq_and_init_vectors()
     replay_vectors("list", ["Uniform", 0.0, 10000.0], 1000.0, 200)

@@ -123,6 +123,24 @@ def test_forward_edge_sizes(gpu_engine, cpu_engine, oracle_mod):
     assert (np.isfinite(sg) == np.isfinite(sc)).all() and not np.isfinite(sg[0])
 
 
+def test_non_default_attributes_against_the_reference(gpu_engine, oracle_mod, golden):
+    """The reference's own trajectories with every model attribute off its default (tests/golden/forward_nondefault.*):
+    DOP853 mode on the GPU reproduces them; the RK4 path converges to them (S = 8)."""
+    g, meta = golden.npz("forward_nondefault"), golden.json("forward_nondefault")
+    for damping in (True, False):
+        cases = [c for c in meta["cases"] if c["damping"] == damping]
+        dc = np.array([c["dc"] for c in cases])
+        ref = np.stack([g[c["tag"]] for c in cases], axis=1)
+        for integrator, S, tol in (("dop853", 1, 1e-9), ("rk4", 8, 2e-7)):
+            m = oracle_mod.ModelSpec(meta["number_time_steps"], meta["start_time"], meta["end_time"], S)
+            for k, v in meta["attrs"].items():
+                setattr(m, k, v)
+            m.RadiationDamping, m.integrator = damping, integrator
+            assert gpu_engine.set_model(m, S) == ref.shape[0]
+            _, acc = gpu_engine.forward(dc)
+            assert _traj_err(acc, ref) < tol, (integrator, damping, _traj_err(acc, ref))
+
+
 @pytest.mark.parametrize("integrator", ["rk4", "dop853"])
 def test_forward_smallest_series(gpu_engine, cpu_engine, oracle_mod, integrator):
     """nout = 2, 3, 4, 5: only the odd last step / one pair / pair + odd step / two pairs of the hot loop run."""

@@ -109,6 +109,39 @@ def test_c_oracle_with_non_default_model_constants(cpu_engine, oracle_mod):
     assert _traj_err(acc, ref) < 1e-10
 
 
+def _nondefault_model(oracle_mod, meta, damping, substeps=1, integrator="rk4"):
+    m = oracle_mod.ModelSpec(meta["number_time_steps"], meta["start_time"], meta["end_time"], substeps)
+    for k, v in meta["attrs"].items():
+        setattr(m, k, v)
+    m.RadiationDamping, m.integrator = damping, integrator
+    return m
+
+
+def test_non_default_attributes_against_the_reference(cpu_engine, oracle_mod, golden):
+    """forward_nondefault.*: the REFERENCE run with V_ref = 1.7, mu_ref = 0.55, mu_t_zero = 0.58, k1 = 3e-7, t_start = 1.5
+    ...  The DOP853 restatement (C) and the SciPy twin must reproduce it like the default cases; the RK4 restatement
+    converges to it at fourth order."""
+    g, meta = golden.npz("forward_nondefault"), golden.json("forward_nondefault")
+    for case in meta["cases"]:
+        ref = g[case["tag"]]
+        m = _nondefault_model(oracle_mod, meta, case["damping"], integrator="dop853")
+        assert cpu_engine.set_model(m, 1) == case["nout"] == len(ref)
+        _, acc = cpu_engine.forward([case["dc"]])
+        assert np.abs(acc[:, 0] - ref).max() <= 1e-11 * np.abs(ref).max(), case["tag"]
+        twin = oracle_mod.forward_dop853(m, case["dc"])
+        assert np.abs(twin - ref).max() <= 1e-11 * np.abs(ref).max(), case["tag"]
+        prev = None
+        for S in (2, 4, 8):
+            mr = _nondefault_model(oracle_mod, meta, case["damping"], substeps=S)
+            cpu_engine.set_model(mr, S)
+            _, acc = cpu_engine.forward([case["dc"]])
+            err = np.abs(acc[:, 0] - ref).max() / np.abs(ref).max()
+            if prev is not None and err > 5e-9:
+                assert 11 <= prev / err <= 21, (case["tag"], S, prev / err)
+            prev = err
+        assert prev < 2e-7, (case["tag"], prev)
+
+
 def test_ssq_grid_against_reference(cpu_engine, oracle_mod, golden):
     g = golden.npz("ssq")
     big = g["qgrid"] >= 700.0  # the S = 1 ladder value (7.4e-5) is for Dc >~ 100-1000; smaller Dc is stiffer
