@@ -139,11 +139,15 @@ class MCMC:
         qparams[0, 0] = self.qstart
         std2 = list(self.std2)
         iaccept = 0
+        # the host needs the current point and proposal variance only to know whether the reference would draw u
+        # (in-bounds test): q follows from the trace row, V changes only where the chain adapts
+        q_state, _, _, V_state = eng.get_state()
+        q_cur, v_cur = float(q_state[0, 0]), float(V_state[0, 0, 0])
+        adapts = self._adapt_mode() != "none"
         for isample in range(self.nsamples):
-            q_cur, _, _, V = eng.get_state()
             z = np.random.standard_normal()  # the single normal multivariate_normal consumes (MCMC.py:497)
             with np.errstate(invalid="ignore"):
-                q_new = float(q_cur[0, 0]) + np.sqrt(float(V[0, 0, 0])) * z
+                q_new = q_cur + np.sqrt(v_cur) * z
             u = 1.0
             if q_new > lo and q_new < hi:  # the reference draws u only for in-bounds proposals
                 if burn:
@@ -153,8 +157,11 @@ class MCMC:
             tq, ts, ta = eng.mcmc_replay(np.array([[[z]]]), np.array([[u]]), np.array([[g]]))
             accept = bool(ta[0, 0])
             iaccept += accept
-            qparams[0, isample + 1] = tq[0, 0, 0]
+            q_cur = float(tq[0, 0, 0])
+            qparams[0, isample + 1] = q_cur
             std2.append(float(ts[0, 0]))
+            if adapts and (isample + 1) % self.adapt_interval == 0:
+                v_cur = float(eng.get_state()[3][0, 0, 0])
             if self.verbose:
                 print(isample, accept)
                 print("Generated Sample ---- ", q_new)

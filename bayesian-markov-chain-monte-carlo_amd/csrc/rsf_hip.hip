@@ -591,6 +591,19 @@ struct rsf_ctx {
   // while launch k+1 computes
   hipStream_t copy_stream = nullptr;
   hipEvent_t ev_done[2] = {nullptr, nullptr};
+  // one-proposal replay as a captured graph (the drop-in single-chain MCMC.sample() is launch-bound)
+  struct ReplayGraph {
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    hipGraphNode_t kernel = nullptr;
+    void *host = nullptr;   // pinned: [z C*d][u C][g C] | [tq C*d][ts C][ta C bytes]
+    void *dev = nullptr;
+    int64_t C = 0;
+    int d = 0;
+    const void *fn = nullptr;
+    size_t lds = 0;
+    int block = 0;
+  } rg;
   // posterior-pool communicator (one process per GPU)
   int32_t world = 0, rank = 0;  // world 0: rsf_comm_init not called
   ncclComm_t comm = nullptr;
@@ -752,6 +765,89 @@ int run_mcmc_drained(rsf_ctx *c, const Consts &K, McmcArgs A, int64_t per, doubl
   return finish(c);
 }
 
+constexpr int64_t kReplayGraphMaxChains = 4096;  // beyond this the copies dominate and the plain path is as good
+
+template <int D, bool DAMP>
+const void *replay_kernel_m(const rsf_ctx *c) {
+  switch (mode_of(c)) {
+    case RK4_F32: return (const void *)mcmc_kernel<D, DAMP, true, RK4_F32>;
+    case DOP853: return (const void *)mcmc_kernel<D, DAMP, true, DOP853>;
+    default: return (const void *)mcmc_kernel<D, DAMP, true, RK4_F64>;
+  }
+}
+
+const void *replay_kernel(const rsf_ctx *c) {
+  const bool damp = c->m.flags & RSF_FLAG_RADIATION_DAMPING;
+  if (c->mc.n_params == 1) return damp ? replay_kernel_m<1, true>(c) : replay_kernel_m<1, false>(c);
+  return damp ? replay_kernel_m<3, true>(c) : replay_kernel_m<3, false>(c);
+}
+
+void release_replay_graph(rsf_ctx *c) {
+  auto &g = c->rg;
+  if (g.exec) (void)hipGraphExecDestroy(g.exec);
+  if (g.graph) (void)hipGraphDestroy(g.graph);
+  if (g.host) (void)hipHostFree(g.host);
+  if (g.dev) (void)hipFree(g.dev);
+  g = rsf_ctx::ReplayGraph{};
+}
+
+// ONE replayed proposal per call from host memory — what the drop-in MCMC.sample() does a thousand times, each call
+// otherwise being three small H2D copies, a 0.1 ms kernel, three D2H copies and a synchronise.  The sequence is a
+// three-node hipGraph (H2D of one pinned input block, the kernel, D2H of one pinned output block) instantiated once per
+// (chains, parameters, kernel) and relaunched with fresh kernel arguments: one runtime call per proposal instead of seven.
+int run_replay_graph(rsf_ctx *c, const Consts &K, McmcArgs A, const double *z, const double *u, const double *g, double *tq,
+                     double *ts, uint8_t *ta) {
+  auto &G = c->rg;
+  const int d = c->mc.n_params;
+  const size_t C = (size_t)A.C;
+  const size_t in_bytes = (C * d + 2 * C) * sizeof(double), out_bytes = (C * d + C) * sizeof(double) + C;
+  const size_t out_off = (in_bytes + 255) & ~(size_t)255, total = out_off + ((out_bytes + 255) & ~(size_t)255);
+  const void *fn = replay_kernel(c);
+  char *hb = (char *)G.host, *db = (char *)G.dev;
+  const bool rebuild = !G.exec || G.C != A.C || G.d != d || G.fn != fn || G.lds != c->lds_bytes || G.block != c->block;
+  if (rebuild) {
+    release_replay_graph(c);
+    HIP_TRY(hipHostMalloc(&G.host, total, hipHostMallocDefault));
+    HIP_TRY(hipMalloc(&G.dev, total));
+    hb = (char *)G.host; db = (char *)G.dev;
+  }
+  A.z = (const double *)db; A.u = A.z + C * d; A.g = A.u + C;
+  A.tq = tq ? (double *)(db + out_off) : nullptr;
+  A.ts = ts ? (double *)(db + out_off) + C * d : nullptr;
+  A.ta = ta ? (uint8_t *)((double *)(db + out_off) + C * d + C) : nullptr;
+  Consts Kc = K;
+  void *params[2] = {&Kc, &A};
+  hipKernelNodeParams kp{};
+  kp.func = const_cast<void *>(fn);
+  kp.gridDim = dim3(grid_for(c, A.C)); kp.blockDim = dim3(c->block);
+  kp.sharedMemBytes = (unsigned)c->lds_bytes;
+  kp.kernelParams = params;
+  kp.extra = nullptr;
+  if (rebuild) {
+    hipGraphNode_t h2d, d2h;
+    HIP_TRY(hipGraphCreate(&G.graph, 0));
+    HIP_TRY(hipGraphAddMemcpyNode1D(&h2d, G.graph, nullptr, 0, db, hb, in_bytes, hipMemcpyHostToDevice));
+    HIP_TRY(hipGraphAddKernelNode(&G.kernel, G.graph, &h2d, 1, &kp));
+    HIP_TRY(hipGraphAddMemcpyNode1D(&d2h, G.graph, &G.kernel, 1, hb + out_off, db + out_off, out_bytes, hipMemcpyDeviceToHost));
+    HIP_TRY(hipGraphInstantiate(&G.exec, G.graph, nullptr, nullptr, 0));
+    G.C = A.C; G.d = d; G.fn = fn; G.lds = c->lds_bytes; G.block = c->block;
+  } else {
+    HIP_TRY(hipGraphExecKernelNodeSetParams(G.exec, G.kernel, &kp));
+  }
+  double *hz = (double *)hb;
+  std::memcpy(hz, z, C * d * sizeof(double));
+  std::memcpy(hz + C * d, u, C * sizeof(double));
+  std::memcpy(hz + C * d + C, g, C * sizeof(double));
+  HIP_TRY(hipGraphLaunch(G.exec, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  const double *ho = (const double *)(hb + out_off);
+  if (tq) std::memcpy(tq, ho, C * d * sizeof(double));
+  if (ts) std::memcpy(ts, ho + C * d, C * sizeof(double));
+  if (ta) std::memcpy(ta, (const uint8_t *)(ho + C * d + C), C);
+  c->iters_done += 1;
+  return RSF_OK;
+}
+
 int run_mcmc(rsf_ctx *c, int64_t n_iters, const double *z, const double *u, const double *g, double *tq,
              double *ts, uint8_t *ta, bool replay) {
   if (!c || n_iters < 0) return fail(RSF_ERR_INVALID, "rsf_mcmc_run: bad argument");
@@ -772,6 +868,11 @@ int run_mcmc(rsf_ctx *c, int64_t n_iters, const double *z, const double *u, cons
   A.wref = (double *)c->wref.p; A.wsum = (double *)c->wsum.p; A.wsq = (double *)c->wsq.p; A.wn = (int32_t *)c->wn.p;
   A.stats = (unsigned long long *)c->stats.p;
   int rc;
+  if (replay && host_mem(c) && n_iters == 1 && C <= kReplayGraphMaxChains) {
+    Consts Kg = make_consts(c, (const double *)c->data.p);
+    Kg.group_chains = c->group_chains;
+    return run_replay_graph(c, Kg, A, z, u, g, tq, ts, ta);
+  }
   const void *dz = nullptr, *du = nullptr, *dg = nullptr;
   void *dtq = nullptr, *dts = nullptr, *dta = nullptr;
   if ((rc = stage_in(c, 0, z, rows * d * sizeof(double), &dz))) return rc;
@@ -903,6 +1004,7 @@ int rsf_destroy(rsf_ctx *c) {
     release(c->vl);
     for (auto &s : c->stage) release(s);
     release(c->pool);
+    release_replay_graph(c);
     if (c->comm) { const Rccl *R = rccl(); if (R) (void)R->comm_destroy(c->comm); }
     for (auto &e : c->ev_done) if (e) (void)hipEventDestroy(e);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
