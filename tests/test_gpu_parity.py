@@ -422,6 +422,46 @@ def test_replay_three_parameters(gpu_engine, cpu_engine, oracle_mod):
     assert 0.05 < tg[2].mean() < 0.98 and same.any()
 
 
+@pytest.mark.parametrize("d", [1, 3])
+def test_one_proposal_replay_graph_equals_plain_replay(pkg, oracle_mod, d):
+    """A one-iteration rsf_mcmc_replay from host memory runs as a hipGraph (pinned blocks + kernel node with updated
+    arguments); six such calls must give the rows and the final state of one six-iteration call (plain path), also
+    across a change of the chain count (graph rebuilt) and with trace arrays left out."""
+    m = _models(oracle_mod, 500)
+    rng = np.random.default_rng(21)
+    n = 6
+    for C in (70, 33):
+        z, u, g = rng.standard_normal((n, C, d)), rng.uniform(size=(n, C)), rng.gamma(250.005, size=(n, C))
+        q0 = np.tile(np.array([1000.0, 0.011, 0.014][:d]), (C, 1))
+        lo, hi = [0.0, 0.005, 0.005][:d], [1e4, 0.02, 0.03][:d]
+        V0 = np.tile(np.diag(np.array([25.0 ** 2, 1e-4 ** 2, 1e-4 ** 2][:d])), (C, 1, 1))
+        with pkg.Engine(mem="host") as e:
+            e.set_model(m, 1)
+            data = synthetic_data(e)
+
+            def start():
+                e.mcmc_init(q0, data, lo, hi, seed=1, adapt_mode="am", adapt_interval=4)
+                e.set_state(V=V0)
+
+            start()
+            plain = e.mcmc_replay(z, u, g)
+            st_plain = e.get_state()
+            start()
+            rows = [e.mcmc_replay(z[k:k + 1], u[k:k + 1], g[k:k + 1], traces=True if k % 2 else ("q", "accept")) for k in range(n)]
+            st_graph = e.get_state()
+            assert e.stats()["iters_done"] == n
+        assert 0 < plain[2].sum() < plain[2].size  # some accepted, some rejected
+        for k in range(n):
+            np.testing.assert_array_equal(rows[k][0][0], plain[0][k])
+            np.testing.assert_array_equal(rows[k][2][0], plain[2][k])
+            if k % 2:
+                np.testing.assert_array_equal(rows[k][1][0], plain[1][k])
+            else:
+                assert rows[k][1] is None
+        for a, b in zip(st_plain, st_graph):
+            np.testing.assert_array_equal(a, b)
+
+
 def test_pool_summary_and_kde(pkg, cpu_engine):
     """Device reductions over pooled samples vs the oracle and scipy.stats.gaussian_kde (host and device buffers)."""
     import torch
