@@ -5,9 +5,9 @@
 // order error estimators), step-size control with safety 0.9 and factors 0.3 .. 6 (beta = 0), at most 500 steps per
 // call, HMAX = interval length, HINIT on the first call and the predicted step size carried from call to call
 // (scipy keeps it in the work array).  After the first interval every call is normally ONE accepted step of
-// length delta_t, so lanes stay convergent.  The RHS is evaluated in full (including the loading velocity at the
-// stage time) — this mode is for fidelity to the reference's numbers (agreement ~1e-12 with its trajectories),
-// the fixed-step RK4 path is the fast one.  Tableau: include/rsf_dop853_tableau.h (generated from SciPy's table).
+// length delta_t, so lanes stay convergent.  The RHS is evaluated in full at the end points of every step and
+// incrementally from the step's start point at its eleven inner stages (friction_incr) — this mode is for fidelity to the
+// reference's numbers (agreement ~1e-12 with its trajectories), the fixed-step RK4 path is the fast one.  Tableau: include/rsf_dop853_tableau.h (generated from SciPy's table).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -29,18 +29,70 @@ __device__ __forceinline__ double loading(const Consts &K, double t) {
   return K.V_ref * (1.0 + fm::exp(t * (-1.0 / 20.0)) * ::sin(10.0 * t));
 }
 
-// RateStateModel.py:318-355 given the loading velocity vl at the evaluation time
+// slip rate and 1/theta at a point: what an incremental evaluation near that point starts from
+struct Base {
+  double v, rth;
+};
+
+// the derivative once v and 1/theta are known (RateStateModel.py:331-353)
 template <bool DAMP>
-__device__ __forceinline__ void friction(const Consts &K, const LaneD &L, double vl, const double y[3], double f[3]) {
-  const double v = K.V_ref * fm::exp(L.inv_a * (y[0] - K.mu_ref - L.b * fm::log(K.V_ref * y[1] * L.inv_dc)));
-  f[1] = 1.0 - v * y[1] * L.inv_dc;
+__device__ __forceinline__ void friction_tail(const Consts &K, const LaneD &L, double vl, double v, double rth, double theta,
+                                              double f[3]) {
+  f[1] = 1.0 - v * theta * L.inv_dc;
   f[0] = L.kprime * (vl - v);
-  const double bt = L.b * fm::rcp(y[1]) * f[1], va = v * L.inv_a;
+  const double bt = L.b * rth * f[1], va = v * L.inv_a;
   f[2] = va * (f[0] - bt);
   if (DAMP) {
     f[0] = f[0] - K.k1 * f[2];
     f[2] = va * (f[0] - bt);
   }
+}
+
+// RateStateModel.py:318-355 given the loading velocity vl at the evaluation time
+template <bool DAMP>
+__device__ __forceinline__ void friction(const Consts &K, const LaneD &L, double vl, const double y[3], double f[3], Base &b) {
+  b.v = K.V_ref * fm::exp(L.inv_a * (y[0] - K.mu_ref - L.b * fm::log(K.V_ref * y[1] * L.inv_dc)));
+  b.rth = fm::rcp(y[1]);
+  friction_tail<DAMP>(K, L, vl, b.v, b.rth, y[1], f);
+}
+
+template <bool DAMP>
+__device__ __forceinline__ void friction(const Consts &K, const LaneD &L, double vl, const double y[3], double f[3]) {
+  Base b;
+  friction<DAMP>(K, L, vl, y, f, b);
+}
+
+// The same derivative at a stage point ys = y + (dmu, dth, .) of a step whose start point has slip rate / reciprocal
+// state b0: v = b0.v exp(dlt), dlt = (dmu - b log1p(rho))/a, rho = dth/theta — by the series of rsf_device.h's NARROW
+// tier (log1p to rho^6/6, expm1 to dlt^7/5040, 1/theta by one Newton step; truncation < 1e-19) inside |rho| < 2^-9,
+// |dlt| < 2^-6, and by the full evaluation outside (per lane).  A DOP853 step spans one output interval, so its
+// stage increments are those of an RK4 step: the full log/exp is needed only at the step's end points.
+template <bool DAMP>
+__device__ __forceinline__ void friction_incr(const Consts &K, const LaneD &L, double vl, const Base &b0, double dmu, double dth,
+                                              const double ys[3], double f[3]) {
+  const double rho = dth * b0.rth;
+  double p = -1.0 / 6.0;
+  p = __builtin_fma(p, rho, 1.0 / 5.0);
+  p = __builtin_fma(p, rho, -1.0 / 4.0);
+  p = __builtin_fma(p, rho, 1.0 / 3.0);
+  p = __builtin_fma(p, rho, -0.5);
+  p = __builtin_fma(p, rho, 1.0);
+  const double dlt = L.inv_a * __builtin_fma(-L.b, p * rho, dmu);
+  if (__builtin_expect(!(__builtin_fabs(rho) < 0x1.0p-9 && __builtin_fabs(dlt) < 0x1.0p-6), 0)) {
+    friction<DAMP>(K, L, vl, ys, f);
+    return;
+  }
+  double e = 1.0 / 5040.0;
+  e = __builtin_fma(e, dlt, 1.0 / 720.0);
+  e = __builtin_fma(e, dlt, 1.0 / 120.0);
+  e = __builtin_fma(e, dlt, 1.0 / 24.0);
+  e = __builtin_fma(e, dlt, 1.0 / 6.0);
+  e = __builtin_fma(e, dlt, 0.5);
+  e = __builtin_fma(e, dlt, 1.0);
+  const double v = __builtin_fma(b0.v * dlt, e, b0.v);
+  double rth = __builtin_fma(b0.rth, __builtin_fma(rho, rho, -rho), b0.rth);
+  rth = __builtin_fma(rth, __builtin_fma(-ys[1], rth, 1.0), rth);
+  friction_tail<DAMP>(K, L, vl, v, rth, ys[1], f);
 }
 
 template <bool DAMP>
@@ -74,15 +126,24 @@ __device__ __forceinline__ double hinit(const Consts &K, const LaneD &L, double 
 // clipped to h = xend - x, which is what every call after the first interval takes; x and xend are the
 // accumulated grid times shared by all lanes, so the host can tabulate them bit-exactly (rsf_set_model).
 // Any other step (HINIT's first interval, steps after a rejection) evaluates V_l(t) directly.
+// `kf` carries the derivative at (x, y) from call to call: every call starts by evaluating the RHS at its start point
+// (SciPy does), which is the point — and, for the tabulated standard step, bit for bit the value — at which the
+// previous call's last accepted step ended (first-same-as-last); have_kf = false on the first call.
 template <bool DAMP>
 __device__ __forceinline__ bool call(const Consts &K, const LaneD &L, const double *tab, double &x, double xend, double y[3],
-                                     double &hc) {
+                                     double &hc, double kf[3], Base &bf, bool &have_kf) {
   constexpr double safe = 0.9, facc1 = 1.0 / 0.3, facc2 = 1.0 / 6.0, uround = 2.3e-16;
   const double hmax = fabs(xend - x);
   double k[12][3], ys[3], k5[3];
   double h = hc;
   bool last = false, reject = false;
-  friction<DAMP>(K, L, tab[0], y, k[0]);  // V_l(x): x is the interval's start time for every lane
+  Base b0 = bf;  // slip rate and 1/theta at (x, y): the stages of a step are evaluated incrementally from it
+  if (have_kf) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) k[0][i] = kf[i];
+  } else {
+    friction<DAMP>(K, L, tab[0], y, k[0], b0);  // V_l(x): x is the interval's start time for every lane
+  }
   if (h == 0.0) h = hinit<DAMP>(K, L, x, y, k[0], hmax);
   for (int nstep = 0;; ) {
     if (nstep > 500) return false;
@@ -92,16 +153,18 @@ __device__ __forceinline__ bool call(const Consts &K, const LaneD &L, const doub
     ++nstep;
 #pragma unroll
     for (int st = 1; st < 12; ++st) {
+      double inc[3];
 #pragma unroll
       for (int i = 0; i < 3; ++i) {
         double s = 0.0;
 #pragma unroll
         for (int j = 0; j < st; ++j)
           if (RSF_DP_A[st - 1][j] != 0.0) s += RSF_DP_A[st - 1][j] * k[j][i];
-        ys[i] = y[i] + h * s;
+        inc[i] = h * s;
+        ys[i] = y[i] + inc[i];
       }
       const double vl = standard ? tab[st] : loading(K, st == 11 ? x + h : x + RSF_DP_C[st] * h);
-      friction<DAMP>(K, L, vl, ys, k[st]);
+      friction_incr<DAMP>(K, L, vl, b0, inc[0], inc[1], ys, k[st]);
     }
     double err = 0.0, err2 = 0.0;
 #pragma unroll
@@ -115,26 +178,36 @@ __device__ __forceinline__ bool call(const Consts &K, const LaneD &L, const doub
         e5 += RSF_DP_E5[j] * kj;
       }
       k5[i] = y[i] + h * s;
-      const double sk = kAtol + kRtol * fmax(fabs(y[i]), fabs(k5[i]));
-      err2 += (e3 / sk) * (e3 / sk);
-      err += (e5 / sk) * (e5 / sk);
+      // Step-size control: the error norm and the step-size factor only steer h (and the accept test err <= 1), so
+      // they use the kernel's reciprocal / log / exp (<= 4 ulp from the divisions and pow of the Fortran code, a fifth
+      // of their instructions); the solution itself (k5) is formed exactly as before.
+      const double isk = fm::rcp(kAtol + kRtol * fmax(fabs(y[i]), fabs(k5[i])));
+      err2 += (e3 * isk) * (e3 * isk);
+      err += (e5 * isk) * (e5 * isk);
     }
     double deno = err + 0.01 * err2;
     if (deno <= 0.0) deno = 1.0;
-    err = fabs(h) * err * sqrt(1.0 / (3.0 * deno));
-    const double fac11 = pow(err, 1.0 / 8.0);
-    double hnew = h / fmax(facc2, fmin(facc1, fac11 / safe));
+    err = fabs(h) * err * sqrt(fm::rcp(3.0 * deno));
+    const double fac11 = err > 0.0 ? fm::exp(0.125 * fm::log(err)) : (err == 0.0 ? 0.0 : err);  // err ** (1/8); NaN stays NaN
+    double hnew = h * fm::rcp(fmax(facc2, fmin(facc1, fac11 * (1.0 / safe))));
     if (err <= 1.0) {
-      friction<DAMP>(K, L, standard ? tab[11] : loading(K, x + h), k5, k[0]);  // first-same-as-last, at x + h
+      friction<DAMP>(K, L, standard ? tab[11] : loading(K, x + h), k5, k[0], b0);  // first-same-as-last, at x + h: full
 #pragma unroll
       for (int i = 0; i < 3; ++i) y[i] = k5[i];
       x = x + h;
-      if (last) { hc = hnew; return true; }
+      if (last) {
+        hc = hnew;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) kf[i] = k[0][i];
+        bf = b0;
+        have_kf = true;
+        return true;
+      }
       if (fabs(hnew) > hmax) hnew = hmax;
       if (reject) hnew = fmin(fabs(hnew), fabs(h));
       reject = false;
     } else {
-      hnew = h / fmin(facc1, fac11 / safe);
+      hnew = h * fm::rcp(fmin(facc1, fac11 * (1.0 / safe)));
       reject = true;
       last = false;
     }
@@ -165,8 +238,9 @@ __device__ __forceinline__ double solve(double *lds, const Consts &K, bool resid
   L.inv_dc = 1.0 / dc; L.kprime = (1e-2 * 10) / dc; L.inv_a = 1.0 / a; L.b = b;
   const double delta_t = K.dt, inv_dt = K.inv_dt;
   double y[3] = {K.mu0, dc / K.V_ref, K.V_ref};
-  double x = K.t0, vprev = K.V_ref, hc = 0.0, ssq = 0.0;
-  bool failed = false;
+  double x = K.t0, vprev = K.V_ref, hc = 0.0, ssq = 0.0, kf[3] = {0.0, 0.0, 0.0};
+  Base bf = {0.0, 0.0};
+  bool failed = false, have_kf = false;
   if (WANT_SSQ && active) { const double d0 = K.data[0]; ssq = d0 * d0; }
   if (WANT_ACC && active) acc_out[0] = 0.0;
   const double *ld = lds + lds_data_offset_dp(K);
@@ -177,7 +251,7 @@ __device__ __forceinline__ double solve(double *lds, const Consts &K, bool resid
     for (int kk = 0; kk < kn; ++kk) {
       double ak = 0.0;  // after a failed call the reference's arrays keep their zeros (RateStateModel.py:361-381)
       if (!failed) {
-        failed = !call<DAMP>(K, L, lds + kTab * kk, x, x + delta_t, y, hc);
+        failed = !call<DAMP>(K, L, lds + kTab * kk, x, x + delta_t, y, hc, kf, bf, have_kf);
         ak = (y[2] - vprev) * inv_dt;
         vprev = y[2];
       }

@@ -187,7 +187,9 @@ __global__ void __launch_bounds__(kMaxBlock) init_dp_kernel(Consts K, InitArgs A
   }
   rsf::dp::LaneD L[D + 1];
   double y[D + 1][3], x[D + 1], hc[D + 1], vprev[D + 1], inv_den[D];
-  bool failed[D + 1];
+  bool failed[D + 1], have_kf[D + 1];
+  double kfs[D + 1][3];
+  rsf::dp::Base bfs[D + 1];
 #pragma unroll
   for (int t = 0; t <= D; ++t) {
     double pq[3] = {p0[0], p0[1], p0[2]};
@@ -197,7 +199,7 @@ __global__ void __launch_bounds__(kMaxBlock) init_dp_kernel(Consts K, InitArgs A
     }
     L[t].inv_dc = 1.0 / pq[0]; L[t].kprime = (1e-2 * 10) / pq[0]; L[t].inv_a = 1.0 / pq[1]; L[t].b = pq[2];
     y[t][0] = K.mu0; y[t][1] = pq[0] / K.V_ref; y[t][2] = K.V_ref;
-    x[t] = K.t0; hc[t] = 0.0; vprev[t] = K.V_ref; failed[t] = false;
+    x[t] = K.t0; hc[t] = 0.0; vprev[t] = K.V_ref; failed[t] = false; have_kf[t] = false;
   }
   double xtx[D * D];
 #pragma unroll
@@ -216,7 +218,7 @@ __global__ void __launch_bounds__(kMaxBlock) init_dp_kernel(Consts K, InitArgs A
       for (int t = 0; t <= D; ++t) {
         ak[t] = 0.0;
         if (!failed[t]) {
-          failed[t] = !rsf::dp::call<DAMP>(K, L[t], lds + rsf::dp::kTab * kk, x[t], x[t] + delta_t, y[t], hc[t]);
+          failed[t] = !rsf::dp::call<DAMP>(K, L[t], lds + rsf::dp::kTab * kk, x[t], x[t] + delta_t, y[t], hc[t], kfs[t], bfs[t], have_kf[t]);
           ak[t] = (y[t][2] - vprev[t]) * K.inv_dt;
           vprev[t] = y[t][2];
         }
