@@ -174,6 +174,12 @@ def main():
                     help="collective backend for N > 1 (nccl = RCCL; gloo only to rehearse the N > 1 path on one GPU)")
     args = ap.parse_args()
 
+    # stdout carries exactly ONE line, the result: everything any library prints meanwhile (RCCL's version banner at the
+    # first communicator, for one) goes to stderr — file descriptor 1 is pointed at stderr until the line is written
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
 
@@ -274,7 +280,10 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["reference_scheme"] = reference_scheme_rate(model, data, C, nsteps)
             out["cpu_baseline"] = cpu_baseline(model, data)
+        sys.stdout.flush()
+        os.dup2(result_fd, 1)
         print(json.dumps(out), flush=True)
+        os.dup2(2, 1)
     if abi_pool is not None and abi_pool.get("status") == "timeout":
         os._exit(0)  # a rank stuck inside a collective cannot be torn down cleanly; the result line is out
     eng.close()
