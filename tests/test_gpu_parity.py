@@ -462,6 +462,36 @@ def test_one_proposal_replay_graph_equals_plain_replay(pkg, oracle_mod, d):
             np.testing.assert_array_equal(a, b)
 
 
+def test_two_ctxs_from_two_threads(pkg, oracle_mod):
+    """rsf_abi.h: a ctx is single-owner, distinct ctxs are independent — two host threads, each with its own ctx
+    (host-memory mode, so every call stages and synchronises), must reproduce their sequential results."""
+    import threading
+
+    m = _models(oracle_mod, 500)
+    with pkg.Engine(mem="host") as e:
+        e.set_model(m, 1)
+        data = synthetic_data(e)
+
+    def job(seed, C, out):
+        with pkg.Engine(mem="host") as e:
+            e.set_model(m, 1)
+            e.mcmc_init(np.full((C, 1), 1000.0), data, [0.0], [1e4], seed=seed, prior_len=3)
+            out[seed] = [e.mcmc_run(7) for _ in range(3)]
+
+    seq, par = {}, {}
+    job(1, 500, seq)
+    job(2, 300, seq)
+    ts = [threading.Thread(target=job, args=(1, 500, par)), threading.Thread(target=job, args=(2, 300, par))]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    for seed in (1, 2):
+        for a, b in zip(seq[seed], par[seed]):
+            for k in range(3):
+                np.testing.assert_array_equal(a[k], b[k])
+
+
 def test_pool_summary_and_kde(pkg, cpu_engine):
     """Device reductions over pooled samples vs the oracle and scipy.stats.gaussian_kde (host and device buffers)."""
     import torch
