@@ -170,14 +170,18 @@ int rsf_mcmc_set_state(rsf_ctx *ctx, const double *q, const double *ssq, const d
  * launch.  Draws come from Philox4x32-10 keyed by (seed; global chain id, iteration, slot).
  *   trace_q[n_iters][C][d]   optional: state after each iteration (qparams columns 1..)
  *   trace_std2[n_iters][C]   optional: sigma^2 after each iteration (std2[1:])
- *   trace_accept[n_iters][C] optional: 1 = accepted */
+ *   trace_accept[n_iters][C] optional: 1 = accepted
+ * RSF_MEM_HOST: a run whose trace exceeds ~32 MiB is cut into launches whose rows are copied to the caller's arrays
+ * on a second stream while the next launch computes (same chain: the kernel continues from the stored state). */
 int rsf_mcmc_run(rsf_ctx *ctx, int64_t n_iters, double *trace_q, double *trace_std2,
                  uint8_t *trace_accept);
 
 /* Same iteration logic, consuming caller-supplied variates instead of Philox:
  *   z[n_iters][C][d] standard normals (proposal = q + chol(V) z; d == 1: q + sqrt(V) z)
  *   u[n_iters][C]    uniforms for the accept test (read only when the proposal is in bounds)
- *   g[n_iters][C]    standard Gamma(0.5 (n0 + nout)) variates for the sigma^2 update */
+ *   g[n_iters][C]    standard Gamma(0.5 (n0 + nout)) variates for the sigma^2 update
+ * This is how MCMC.sample() reproduces a np.random.seed chain: one call per proposal with the variates NumPy drew.
+ * (RSF_MEM_HOST, n_iters = 1: the copies and the kernel are one pre-instantiated hipGraph launch.) */
 int rsf_mcmc_replay(rsf_ctx *ctx, int64_t n_iters, const double *z, const double *u,
                     const double *g, double *trace_q, double *trace_std2, uint8_t *trace_accept);
 
