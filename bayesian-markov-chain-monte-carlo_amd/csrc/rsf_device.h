@@ -477,12 +477,12 @@ __device__ __forceinline__ void integrate_tiers(const double *lds, const double 
                                                 int kn, State &s, double &ssq, double *acc_out, int64_t stride) {
   // Wave-uniform choice of the starting tier — a speed decision only: every tier is exact to rounding inside
   // its guard, and a tier whose guard trips redoes that pair in full and hands over to the next wider one.
-  // TIGHT is tried whenever the mu increment allows it (|V_l - v| <~ 1.2): theta tracks its steady state
+  // TIGHT is tried whenever the mu increment allows it (|V_l - v| <~ 1.2 V_ref): theta tracks its steady state
   // closely (|dtheta/theta| ~ 1e-7 per stage at Dc ~ 1000, h = 0.1), which no a-priori bound captures.
 #ifdef RSF_FORCE_NARROW
   const int tier = NARROW;
 #else
-  const int tier = !__any(!(1.2 * K.h * L.kia < 0x1.0p-9)) ? TIGHT : (!__any(!(4.0 * K.h * L.inv_dc < 0x1.0p-9)) ? NARROW : WIDE);
+  const int tier = !__any(!(1.2 * K.V_ref * K.h * L.kia < 0x1.0p-9)) ? TIGHT : (!__any(!(4.0 * K.h * L.vdc < 0x1.0p-9)) ? NARROW : WIDE);
 #endif
   const int nsteps = S1 ? kn : K.S * kn;
   Emit em = {0, 0, s.V};

@@ -106,6 +106,30 @@ def test_forward_with_non_default_model_constants(gpu_engine, cpu_engine, oracle
         _assert_chains_match(tg, tc, min_same=0.98)
 
 
+@pytest.mark.parametrize("integrator", ["rk4", "dop853"])
+def test_forward_is_scale_free_in_v_ref(gpu_engine, cpu_engine, oracle_mod, integrator):
+    """Slip rates in SI units: V_ref = 1e-6 with Dc scaled along (theta_0 = Dc/V_ref unchanged) is the same problem in
+    other units; no absolute threshold in the kernels (tier heuristics, guards) may notice.  (DOP853's atol = 1e-10 is
+    the reference's own absolute tolerance and applies to both sides alike.)"""
+    m = _models(oracle_mod, 500)
+    m.V_ref, m.integrator = 1.0e-6, integrator
+    m.k1 = m.k1 / m.V_ref  # the damping coefficient carries units of 1/velocity: k1 v/a is what must stay the same
+    for e in (gpu_engine, cpu_engine):
+        e.set_model(m, 1)
+    dc = np.array([3.0e-4, 1.0e-3, 2.5e-3, 6.0e-3])
+    data = synthetic_data(cpu_engine, dc_true=1.0e-3)
+    sg, ag = gpu_engine.forward(dc, data=data, want_ssq=True, want_acc=True)
+    sc, ac = cpu_engine.forward(dc, data=data, want_ssq=True, want_acc=True)
+    assert np.isfinite(ac).all() and np.abs(ac).max() < 1e-4
+    assert _traj_err(ag, ac) < RTOL
+    np.testing.assert_allclose(sg, sc, rtol=RTOL)
+    if integrator == "rk4":  # and it IS the V_ref = 1 problem in other units: acc scales with V_ref
+        m1 = _models(oracle_mod, 500)
+        gpu_engine.set_model(m1, 1)
+        _, a1 = gpu_engine.forward(dc * 1.0e6)
+        np.testing.assert_allclose(ag, a1 * 1.0e-6, rtol=1e-9, atol=1e-20)
+
+
 def test_forward_edge_sizes(gpu_engine, cpu_engine, oracle_mod):
     m = _models(oracle_mod, 500)
     for e in (gpu_engine, cpu_engine):
