@@ -486,6 +486,35 @@ def test_one_proposal_replay_graph_equals_plain_replay(pkg, oracle_mod, d):
             np.testing.assert_array_equal(a, b)
 
 
+def test_host_and_device_memory_spaces_agree(pkg, oracle_mod):
+    """RSF_MEM_HOST stages the caller's arrays, RSF_MEM_DEVICE uses them in place: same kernels, same results —
+    forward solve, initial state, a sampler run and the pooled moments."""
+    import torch
+
+    m = _models(oracle_mod, 500)
+    C = 333
+    dc = np.linspace(500.0, 3000.0, C)
+    with pkg.Engine(mem="host") as eh, pkg.Engine(mem="device") as ed:
+        for e in (eh, ed):
+            e.set_model(m, 1)
+        data = synthetic_data(eh)
+        sh, ah = eh.forward(dc, data=data, want_ssq=True, want_acc=True)
+        sd, ad = ed.forward(torch.from_numpy(dc).cuda(), data=torch.from_numpy(data).cuda(), want_ssq=True, want_acc=True)
+        np.testing.assert_array_equal(sh, sd.cpu().numpy())
+        np.testing.assert_array_equal(ah, ad.cpu().numpy())
+        q0 = np.full((C, 1), 1000.0)
+        eh.mcmc_init(q0, data, [0.0], [1e4], seed=8, prior_len=3)
+        ed.mcmc_init(torch.from_numpy(q0).cuda(), torch.from_numpy(data).cuda(), [0.0], [1e4], seed=8, prior_len=3)
+        for a, b in zip(eh.get_state(), ed.get_state()):
+            np.testing.assert_array_equal(a, b.cpu().numpy())
+        th, td = eh.mcmc_run(9), ed.mcmc_run(9)
+        ed.sync()
+        for a, b in zip(th, td):
+            np.testing.assert_array_equal(a, b.cpu().numpy())
+        assert eh.stats() == ed.stats()
+        assert eh.pool_summary(th[0]) == ed.pool_summary(td[0])
+
+
 def test_two_ctxs_from_two_threads(pkg, oracle_mod):
     """rsf_abi.h: a ctx is single-owner, distinct ctxs are independent — two host threads, each with its own ctx
     (host-memory mode, so every call stages and synchronises), must reproduce their sequential results."""
