@@ -317,6 +317,21 @@ def test_out_of_bounds_proposals_skip_the_solve(gpu_engine, cpu_engine, oracle_m
     assert (tg[0] > 980.0).all() and (tg[0] < 1020.0).all()
 
 
+def test_out_of_bounds_with_chunked_tables(gpu_engine, cpu_engine, oracle_mod):
+    """nsteps 4000 x 2 substeps does not fit the LDS budget, so the tables are staged chunk by chunk behind workgroup
+    barriers: waves whose lanes are all out of bounds must still take part in the staging (no divergent barrier), and
+    chains that are in bounds only sometimes must match the oracle."""
+    m = _models(oracle_mod, 4000, 2)
+    for e in (gpu_engine, cpu_engine):
+        e.set_model(m, 2)
+    data = synthetic_data(cpu_engine)
+    C = 300  # 5 waves, the last one ragged; most proposals leave the box
+    tg, tc = _run_pair(gpu_engine, cpu_engine, 6, C, np.full((C, 1), 1000.0), data, [995.0], [1005.0], seed=3, prior_len=3)
+    _assert_chains_match(tg, tc)
+    sg, sc = gpu_engine.stats(), cpu_engine.stats()
+    assert sg["evaluated"] == sc["evaluated"] < C * 6 // 2
+
+
 def _dp(oracle_mod, n, damping=True):
     m = _models(oracle_mod, n, 1, damping)
     m.integrator = "dop853"
