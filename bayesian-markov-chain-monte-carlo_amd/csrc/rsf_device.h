@@ -472,6 +472,70 @@ __device__ __forceinline__ int integrate_pairs(const double *lds, const double *
   return r;
 }
 
+// NU steps per trip through the loop (straight-line code): the resync test, the guard compare and
+// the branch that waits for it, and the LDS addressing are paid per TRIP — and a lone wave sits out the whole latency
+// of that compare-and-branch, ~150 cycles, whatever the trip holds (2 -> 4 -> 8 steps per trip: +12 %, +14 % at cfg1).
+// A tripped guard redoes the trip with full evaluations; TIGHT and NARROW then hand the rest of the chunk to the next
+// wider tier (`tripped`), like integrate_pairs, which takes whatever remainder (< NU steps) is left.
+#ifndef RSF_TIGHT_UNROLL
+#define RSF_TIGHT_UNROLL 8
+#endif
+#ifndef RSF_WIDER_UNROLL
+#define RSF_WIDER_UNROLL 4
+#endif
+template <bool DAMP, bool WANT_SSQ, bool WANT_ACC, int T, bool S1, int NU>
+__device__ __forceinline__ int integrate_multi(const double *lds, const double *ld, const Consts &K, Lane L, int k0, int kn, int r,
+                                               int nsteps, State &s, Emit &em, double &ssq, double *acc_out, int64_t stride,
+                                               bool &tripped) {
+  static_assert(NU >= 2 && (RSF_RESYNC % NU) == 0, "the resync test looks at the first step of a trip");
+  set_tier<T>(L);
+  for (; r + NU <= nsteps; r += NU) {
+    const double *v = lds + 2 * r;
+    // observations this trip can complete, read before the arithmetic (substeps > 1: at most NU/2 samples per trip,
+    // the next ones in line — clamped reads, unused ones cost an LDS read each)
+    constexpr int NO = S1 ? NU : NU / 2;
+    double obs[NO], dv[NU];
+#pragma unroll
+    for (int j = 0; j < NO; ++j) obs[j] = WANT_SSQ ? ld[S1 ? r + j : min(em.ko + j, kn - 1)] : 0.0;
+    if ((r & (RSF_RESYNC - 1)) == 0) eval_full(s.ms, s.x, L, K, s.w, s.rx);
+    const State save = s;
+    Guard g = {0, 0};
+#pragma unroll
+    for (int j = 0; j < NU; ++j) dv[j] = rk4_fast<DAMP, T>(s, v[2 * j], v[2 * j + 1], v[2 * j + 2], L, K, g);
+    const bool bad = !guard_ok<T>(g);
+    const unsigned long long badmask = __builtin_amdgcn_ballot_w64(bad);  // wave-uniform, straight from the compares
+    if (__builtin_expect(badmask != 0, 0)) {  // scalar branch: the hot path carries no exec-mask bookkeeping
+      if (bad) {
+        s = save;
+#pragma unroll 1
+        for (int j = 0; j < NU; ++j) dv[j] = rk4_cold<DAMP>(s, v[2 * j], v[2 * j + 1], v[2 * j + 2], L, K);
+        eval_full(s.ms, s.x, L, K, s.w, s.rx);
+      }
+    }
+    if (S1) {
+#pragma unroll
+      for (int j = 0; j < NU; ++j) emit_incr<WANT_SSQ, WANT_ACC>(dv[j], r + j, obs[j], K, k0, ssq, acc_out, stride);
+    } else {
+      int used = 0;  // wave-uniform: every lane emits the same samples
+      s.V = save.V;
+#pragma unroll
+      for (int j = 0; j < NU; ++j) {
+        s.V = __builtin_fma(K.h6, dv[j], s.V);
+        if (++em.phase == K.S) {
+          em.phase = 0;
+          double o = obs[0];
+#pragma unroll
+          for (int i = 1; i < NO; ++i) o = used == i ? obs[i] : o;
+          emit_sample<WANT_SSQ, WANT_ACC>(s.V, em, o, K, k0, ssq, acc_out, stride);
+          ++used;
+        }
+      }
+    }
+    if (T != WIDE && badmask != 0) { tripped = true; return r + NU; }
+  }
+  return r;
+}
+
 template <bool DAMP, bool WANT_SSQ, bool WANT_ACC, bool S1>
 __device__ __forceinline__ void integrate_tiers(const double *lds, const double *ld, const Consts &K, const Lane &L, int k0,
                                                 int kn, State &s, double &ssq, double *acc_out, int64_t stride) {
@@ -487,8 +551,24 @@ __device__ __forceinline__ void integrate_tiers(const double *lds, const double 
   const int nsteps = S1 ? kn : K.S * kn;
   Emit em = {0, 0, s.V};
   int r = 0;
-  if (tier == TIGHT) r = integrate_pairs<DAMP, WANT_SSQ, WANT_ACC, TIGHT, S1>(lds, ld, K, L, k0, r, nsteps, s, em, ssq, acc_out, stride);
-  if (tier <= NARROW) r = integrate_pairs<DAMP, WANT_SSQ, WANT_ACC, NARROW, S1>(lds, ld, K, L, k0, r, nsteps, s, em, ssq, acc_out, stride);
+  // tiers in order; within a tier the long-trip loop first, then pairs for the remainder;
+  // `t_trip` / `n_trip`: that tier's guard tripped in the long-trip loop, the rest goes to the next wider tier
+  bool t_trip = false, n_trip = false, unused = false;
+  if (tier == TIGHT) {
+#ifndef RSF_NO_MULTI
+    r = integrate_multi<DAMP, WANT_SSQ, WANT_ACC, TIGHT, S1, RSF_TIGHT_UNROLL>(lds, ld, K, L, k0, kn, r, nsteps, s, em, ssq, acc_out, stride, t_trip);
+#endif
+    if (!t_trip) r = integrate_pairs<DAMP, WANT_SSQ, WANT_ACC, TIGHT, S1>(lds, ld, K, L, k0, r, nsteps, s, em, ssq, acc_out, stride);
+  }
+  if (tier <= NARROW) {
+#ifndef RSF_NO_MULTI
+    r = integrate_multi<DAMP, WANT_SSQ, WANT_ACC, NARROW, S1, RSF_WIDER_UNROLL>(lds, ld, K, L, k0, kn, r, nsteps, s, em, ssq, acc_out, stride, n_trip);
+#endif
+    if (!n_trip) r = integrate_pairs<DAMP, WANT_SSQ, WANT_ACC, NARROW, S1>(lds, ld, K, L, k0, r, nsteps, s, em, ssq, acc_out, stride);
+  }
+#ifndef RSF_NO_MULTI
+  r = integrate_multi<DAMP, WANT_SSQ, WANT_ACC, WIDE, S1, RSF_WIDER_UNROLL>(lds, ld, K, L, k0, kn, r, nsteps, s, em, ssq, acc_out, stride, unused);
+#endif
   r = integrate_pairs<DAMP, WANT_SSQ, WANT_ACC, WIDE, S1>(lds, ld, K, L, k0, r, nsteps, s, em, ssq, acc_out, stride);
   if (r < nsteps) {  // odd last step of the chunk (it always completes a sample): one WIDE step, cold if its guard trips
     const double *v = lds + 2 * r;
