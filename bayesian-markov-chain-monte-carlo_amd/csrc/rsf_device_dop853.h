@@ -64,12 +64,14 @@ __device__ __forceinline__ void friction(const Consts &K, const LaneD &L, double
 
 // The same derivative at a stage point ys = y + (dmu, dth, .) of a step whose start point has slip rate / reciprocal
 // state b0: v = b0.v exp(dlt), dlt = (dmu - b log1p(rho))/a, rho = dth/theta — by the series of rsf_device.h's NARROW
-// tier (log1p to rho^6/6, expm1 to dlt^7/5040, 1/theta by one Newton step; truncation < 1e-19) inside |rho| < 2^-9,
-// |dlt| < 2^-6, and by the full evaluation outside (per lane).  A DOP853 step spans one output interval, so its
-// stage increments are those of an RK4 step: the full log/exp is needed only at the step's end points.
+// tier (log1p to rho^6/6, expm1 to dlt^7/5040, 1/theta by one Newton step; truncation < 1e-19), valid inside
+// |rho| < 2^-9, |dlt| < 2^-6.  Outside, `bad` is raised and the caller redoes the step's stages with full evaluations
+// — ONE test per step: a branch per stage would stall a lone wave for the latency of its compare eleven times per
+// step.  A DOP853 step spans one output interval, so its stage increments are those of an RK4 step: the full log/exp
+// is needed only at the step's end points.
 template <bool DAMP>
 __device__ __forceinline__ void friction_incr(const Consts &K, const LaneD &L, double vl, const Base &b0, double dmu, double dth,
-                                              const double ys[3], double f[3]) {
+                                              const double ys[3], double f[3], bool &bad) {
   const double rho = dth * b0.rth;
   double p = -1.0 / 6.0;
   p = __builtin_fma(p, rho, 1.0 / 5.0);
@@ -78,10 +80,7 @@ __device__ __forceinline__ void friction_incr(const Consts &K, const LaneD &L, d
   p = __builtin_fma(p, rho, -0.5);
   p = __builtin_fma(p, rho, 1.0);
   const double dlt = L.inv_a * __builtin_fma(-L.b, p * rho, dmu);
-  if (__builtin_expect(!(__builtin_fabs(rho) < 0x1.0p-9 && __builtin_fabs(dlt) < 0x1.0p-6), 0)) {
-    friction<DAMP>(K, L, vl, ys, f);
-    return;
-  }
+  bad = bad || !(__builtin_fabs(rho) < 0x1.0p-9 && __builtin_fabs(dlt) < 0x1.0p-6);
   double e = 1.0 / 5040.0;
   e = __builtin_fma(e, dlt, 1.0 / 720.0);
   e = __builtin_fma(e, dlt, 1.0 / 120.0);
@@ -151,6 +150,7 @@ __device__ __forceinline__ bool call(const Consts &K, const LaneD &L, const doub
     if (x + 1.01 * h - xend > 0.0) { h = xend - x; last = true; }
     const bool standard = last && nstep == 0;  // the tabulated step
     ++nstep;
+    bool bad = false;
 #pragma unroll
     for (int st = 1; st < 12; ++st) {
       double inc[3];
@@ -164,7 +164,24 @@ __device__ __forceinline__ bool call(const Consts &K, const LaneD &L, const doub
         ys[i] = y[i] + inc[i];
       }
       const double vl = standard ? tab[st] : loading(K, st == 11 ? x + h : x + RSF_DP_C[st] * h);
-      friction_incr<DAMP>(K, L, vl, b0, inc[0], inc[1], ys, k[st]);
+      friction_incr<DAMP>(K, L, vl, b0, inc[0], inc[1], ys, k[st], bad);
+    }
+    if (__builtin_expect(__any(bad), 0)) {  // an increment outside the series' range: this step again, every stage in full
+      if (bad) {
+#pragma unroll
+        for (int st = 1; st < 12; ++st) {
+#pragma unroll
+          for (int i = 0; i < 3; ++i) {
+            double s = 0.0;
+#pragma unroll
+            for (int j = 0; j < st; ++j)
+              if (RSF_DP_A[st - 1][j] != 0.0) s += RSF_DP_A[st - 1][j] * k[j][i];
+            ys[i] = y[i] + h * s;
+          }
+          const double vl = standard ? tab[st] : loading(K, st == 11 ? x + h : x + RSF_DP_C[st] * h);
+          friction<DAMP>(K, L, vl, ys, k[st]);
+        }
+      }
     }
     double err = 0.0, err2 = 0.0;
 #pragma unroll

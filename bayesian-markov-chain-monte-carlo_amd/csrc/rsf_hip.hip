@@ -353,7 +353,8 @@ __global__ void __launch_bounds__(kMaxBlock, MODE == DOP853 ? 1 : RSF_MIN_BLOCKS
       inb = inb && (s > A.lo[p]) && (s < A.hi[p]);  // strict box, MCMC.py:318-320
     }
     // ---- likelihood: forward solve only for in-bounds proposals, MCMC.py:322-324 ----
-    const double an = D == 3 ? qn[D - 2] : K.a_def, bn = D == 3 ? qn[D - 1] : K.b_def;
+    double an = K.a_def, bn = K.b_def;
+    if constexpr (D == 3) { an = qn[1]; bn = qn[2]; }
     double ssqn = 0.0;
     // (a wave with no in-bounds lane skips the solve when the tables are resident: no barrier inside)
     if (!resident || __any(inb)) {
