@@ -63,6 +63,7 @@ struct Lane {
   double hhd, hd, h6d;  // (h/2)/Dc, h/Dc, (h/6)/Dc : theta increments in x units
   double c_l1p;   // leading series coefficients of the active tier, kept in VGPRs (a VOP3 takes one SGPR source and
   double c_em1;   //   the first Horner term has two non-inline constants); see set_tier
+  double c_em1h;  // TIGHT half-step stages: 1/24
 };
 
 template <int T>
@@ -162,6 +163,7 @@ __device__ __forceinline__ void eval_full(double ms, double x, const Lane &L, co
 // by short series — the same function of (ms', x') to rounding inside the tier's guard region:
 //   tier     |rho| <   |dlt| <   log1p to     expm1 to       1/x'                              truncation
 //   TIGHT    2^-20     2^-9      rho^2/2      dlt^5/120      1 - rho + rho^2 (no Newton step)  < 3e-19, rho^3 < 2^-60
+//            (its two half-step stages: |dlt| < 2^-10 and expm1 to dlt^4/24, truncation < 8e-18 relative)
 //   NARROW   2^-9      2^-6      rho^6/6      dlt^7/5040     2nd-order start + 1 Newton step   < 1e-19, rho^6 < 2^-54
 //   WIDE     2^-7      2^-6      rho^7/7      dlt^7/5040     1st-order start + 2 Newton steps  < 1e-19, rho^8 < 2^-56
 // Guard tracks the largest |rho| / |dlt| seen since it was last reset — through the HIGH WORD of each double read as
@@ -186,10 +188,12 @@ __device__ __forceinline__ double stage_t1(double vl, double rx_or_q, double vbr
 #ifdef RSF_GUARD_F64
 struct Guard {
   double rho, dlt;
+  double dlt_h;
 };
 #else
 struct Guard {
   float rho, dlt;
+  float dlt_h;  // TIGHT: |dlt| of the two half-step stages, held to 2^-10 so that their expm1 series is one term shorter
 };
 #endif
 
@@ -202,10 +206,11 @@ template <int T>
 __device__ __forceinline__ void set_tier(Lane &L) {
   L.c_l1p = T == NARROW ? -1.0 / 6.0 : 1.0 / 7.0;  // (TIGHT needs none: 1 - rho/2 has inline constants only)
   L.c_em1 = T == TIGHT ? 1.0 / 120.0 : 1.0 / 5040.0;
-  asm volatile("" : "+v"(L.c_l1p), "+v"(L.c_em1));  // opaque: stays a register value, not re-materialised per step
+  L.c_em1h = 1.0 / 24.0;
+  asm volatile("" : "+v"(L.c_l1p), "+v"(L.c_em1), "+v"(L.c_em1h));  // opaque: stays a register value, not re-materialised per step
 }
 
-template <int T, bool STAGE>
+template <int T, bool STAGE, bool HALF = false>
 __device__ __forceinline__ void eval_incr(double kf, double dms_dt, double R, double dth_dt, double x1, const Lane &L, double w0,
                                           double rx0, double &w, double &rx, Guard &g) {  // TIGHT && STAGE: rx returns q (stage_t1)
   // dk = kf * dms_dt (kf: kia times the step fraction);  rho = R * dth_dt (R: step fraction / Dc / x, once per step)
@@ -231,19 +236,26 @@ __device__ __forceinline__ void eval_incr(double kf, double dms_dt, double R, do
     p = __builtin_fma(p, rho, 1.0);
   }
   const double dlt = __builtin_fma(-(L.boa * rho), p, kf * dms_dt);  // d1 -> rho -> p -> dlt: three deep
+  constexpr bool kShort = T == TIGHT && HALF;  // half-step stage of the TIGHT tier: |dlt| < 2^-10, series to dlt^4/24
 #ifdef RSF_GUARD_F64
-  g.dlt = __builtin_fmax(g.dlt, __builtin_fabs(dlt));
+  if (kShort) g.dlt_h = __builtin_fmax(g.dlt_h, __builtin_fabs(dlt));
+  else g.dlt = __builtin_fmax(g.dlt, __builtin_fabs(dlt));
 #else
-  g.dlt = __builtin_fmaxf(g.dlt, __builtin_fabsf(hi_as_float(dlt)));
+  if (kShort) g.dlt_h = __builtin_fmaxf(g.dlt_h, __builtin_fabsf(hi_as_float(dlt)));
+  else g.dlt = __builtin_fmaxf(g.dlt, __builtin_fabsf(hi_as_float(dlt)));
 #endif
   double e;
-  if (T == TIGHT) {
-    e = L.c_em1;
+  if (kShort) {
+    e = L.c_em1h;
   } else {
-    e = fm::hfma(L.c_em1, dlt, 1.0 / 720.0);
-    e = fm::hfma(e, dlt, 1.0 / 120.0);
+    if (T == TIGHT) {
+      e = L.c_em1;
+    } else {
+      e = fm::hfma(L.c_em1, dlt, 1.0 / 720.0);
+      e = fm::hfma(e, dlt, 1.0 / 120.0);
+    }
+    e = fm::hfma(e, dlt, 1.0 / 24.0);
   }
-  e = fm::hfma(e, dlt, 1.0 / 24.0);
   e = fm::hfma(e, dlt, 1.0 / 6.0);
   e = __builtin_fma(e, dlt, 0.5);
   e = __builtin_fma(e, dlt, 1.0);
@@ -264,10 +276,11 @@ __device__ __forceinline__ void eval_incr(double kf, double dms_dt, double R, do
 template <int T>
 __device__ __forceinline__ bool guard_ok(const Guard &g) {  // NaN passes through (see Guard)
 #ifdef RSF_GUARD_F64
-  return (g.rho < (T == WIDE ? 0x1.0p-7 : (T == NARROW ? 0x1.0p-9 : 0x1.0p-20))) && (g.dlt < (T == TIGHT ? 0x1.0p-9 : 0x1.0p-6));
+  return (g.rho < (T == WIDE ? 0x1.0p-7 : (T == NARROW ? 0x1.0p-9 : 0x1.0p-20))) && (g.dlt < (T == TIGHT ? 0x1.0p-9 : 0x1.0p-6)) &&
+         (T != TIGHT || g.dlt_h < 0x1.0p-10);
 #else
   return (g.rho < (T == WIDE ? hi_pow2(-7) : (T == NARROW ? hi_pow2(-9) : hi_pow2(-20)))) &&
-         (g.dlt < (T == TIGHT ? hi_pow2(-9) : hi_pow2(-6)));
+         (g.dlt < (T == TIGHT ? hi_pow2(-9) : hi_pow2(-6))) && (T != TIGHT || g.dlt_h < hi_pow2(-10));
 #endif
 }
 
@@ -322,10 +335,10 @@ __device__ __forceinline__ double rk4_fast(State &s, double vl0, double vlm, dou
   const double vbr0 = L.vb * s.rx;
   rhs_fast<DAMP>(s.w, s.x, vl0, __builtin_fma(L.vk, vl0, -vbr0), L, K, a0, a1, a2);
   xs = __builtin_fma(L.hhd, a1, s.x);
-  eval_incr<T, true>(L.khh, a0, Rh, a1, xs, L, s.w, s.rx, w, rx, g);
+  eval_incr<T, true, true>(L.khh, a0, Rh, a1, xs, L, s.w, s.rx, w, rx, g);
   rhs_fast<DAMP>(w, xs, vlm, stage_t1<T>(vlm, rx, vbr0, L), L, K, b0, b1, b2);
   xs = __builtin_fma(L.hhd, b1, s.x);
-  eval_incr<T, true>(L.khh, b0, Rh, b1, xs, L, s.w, s.rx, w, rx, g);
+  eval_incr<T, true, true>(L.khh, b0, Rh, b1, xs, L, s.w, s.rx, w, rx, g);
   rhs_fast<DAMP>(w, xs, vlm, stage_t1<T>(vlm, rx, vbr0, L), L, K, c0, c1, c2);
   xs = __builtin_fma(L.hd, c1, s.x);
   eval_incr<T, true>(L.kh, c0, Rf, c1, xs, L, s.w, s.rx, w, rx, g);
@@ -351,7 +364,7 @@ __device__ __forceinline__ void rk4_step(State &s, bool resync, double vl0, doub
 #else
   if (resync) eval_full(s.ms, s.x, L, K, s.w, s.rx);
   const State save = s;
-  Guard g = {0, 0};
+  Guard g = {0, 0, 0};
   double dv = rk4_fast<DAMP, WIDE>(s, vl0, vlm, vl1, L, K, g);
   if (__builtin_expect(!guard_ok<WIDE>(g), 0)) {  // an increment too large (or Inf; NaN passes through): cold path
     s = save;
@@ -445,7 +458,7 @@ __device__ __forceinline__ int integrate_pairs(const double *lds, const double *
     const double obs0 = WANT_SSQ ? ld[S1 ? r : em.ko] : 0.0, obs1 = (WANT_SSQ && S1) ? ld[r + 1] : 0.0;
     if ((r & (RSF_RESYNC - 1)) == 0) eval_full(s.ms, s.x, L, K, s.w, s.rx);
     const State save = s;
-    Guard g = {0, 0};
+    Guard g = {0, 0, 0};
     double dv0 = rk4_fast<DAMP, T>(s, v[0], v[1], v[2], L, K, g);
     double dv1 = rk4_fast<DAMP, T>(s, v[2], v[3], v[4], L, K, g);
     const bool bad = !guard_ok<T>(g);
@@ -499,7 +512,7 @@ __device__ __forceinline__ int integrate_multi(const double *lds, const double *
     for (int j = 0; j < NO; ++j) obs[j] = WANT_SSQ ? ld[S1 ? r + j : min(em.ko + j, kn - 1)] : 0.0;
     if ((r & (RSF_RESYNC - 1)) == 0) eval_full(s.ms, s.x, L, K, s.w, s.rx);
     const State save = s;
-    Guard g = {0, 0};
+    Guard g = {0, 0, 0};
 #pragma unroll
     for (int j = 0; j < NU; ++j) dv[j] = rk4_fast<DAMP, T>(s, v[2 * j], v[2 * j + 1], v[2 * j + 2], L, K, g);
     const bool bad = !guard_ok<T>(g);
@@ -576,7 +589,7 @@ __device__ __forceinline__ void integrate_tiers(const double *lds, const double 
     Lane Lw = L;
     set_tier<WIDE>(Lw);
     const State save = s;
-    Guard g = {0, 0};
+    Guard g = {0, 0, 0};
     double dv = rk4_fast<DAMP, WIDE>(s, v[0], v[1], v[2], Lw, K, g);
     if (__builtin_expect(!guard_ok<WIDE>(g), 0)) {
       s = save;
