@@ -549,7 +549,7 @@ __device__ __forceinline__ int integrate_multi(const double *lds, const double *
   return r;
 }
 
-template <bool DAMP, bool WANT_SSQ, bool WANT_ACC, bool S1>
+template <bool DAMP, bool WANT_SSQ, bool WANT_ACC, bool S1, int NUT>
 __device__ __forceinline__ void integrate_tiers(const double *lds, const double *ld, const Consts &K, const Lane &L, int k0,
                                                 int kn, State &s, double &ssq, double *acc_out, int64_t stride) {
   // Wave-uniform choice of the starting tier — a speed decision only: every tier is exact to rounding inside
@@ -569,7 +569,7 @@ __device__ __forceinline__ void integrate_tiers(const double *lds, const double 
   bool t_trip = false, n_trip = false, unused = false;
   if (tier == TIGHT) {
 #ifndef RSF_NO_MULTI
-    r = integrate_multi<DAMP, WANT_SSQ, WANT_ACC, TIGHT, S1, RSF_TIGHT_UNROLL>(lds, ld, K, L, k0, kn, r, nsteps, s, em, ssq, acc_out, stride, t_trip);
+    r = integrate_multi<DAMP, WANT_SSQ, WANT_ACC, TIGHT, S1, NUT>(lds, ld, K, L, k0, kn, r, nsteps, s, em, ssq, acc_out, stride, t_trip);
 #endif
     if (!t_trip) r = integrate_pairs<DAMP, WANT_SSQ, WANT_ACC, TIGHT, S1>(lds, ld, K, L, k0, r, nsteps, s, em, ssq, acc_out, stride);
   }
@@ -607,17 +607,17 @@ __device__ __forceinline__ void integrate_tiers(const double *lds, const double 
 
 // Integrate kn output intervals from the staged chunk.  Accumulates the sum of squares
 // (MCMC.py:387) and optionally stores acc time-major.  Called under the lane's activity mask.
-template <bool DAMP, bool WANT_SSQ, bool WANT_ACC>
+template <bool DAMP, bool WANT_SSQ, bool WANT_ACC, int NUT>
 __device__ __forceinline__ void integrate_chunk(const double *lds, const Consts &K, const Lane &L, int k0,
                                                 int kn, State &s, double &ssq, double *acc_out, int64_t stride) {
   const double *ld = lds + lds_data_offset(K);
 #ifndef RSF_NO_INCREMENTAL
   if (K.S == 1) {
-    integrate_tiers<DAMP, WANT_SSQ, WANT_ACC, true>(lds, ld, K, L, k0, kn, s, ssq, acc_out, stride);
+    integrate_tiers<DAMP, WANT_SSQ, WANT_ACC, true, NUT>(lds, ld, K, L, k0, kn, s, ssq, acc_out, stride);
     return;
   }
 #ifndef RSF_S1_ONLY
-  integrate_tiers<DAMP, WANT_SSQ, WANT_ACC, false>(lds, ld, K, L, k0, kn, s, ssq, acc_out, stride);
+  integrate_tiers<DAMP, WANT_SSQ, WANT_ACC, false, NUT>(lds, ld, K, L, k0, kn, s, ssq, acc_out, stride);
   return;
 #endif
 #endif
@@ -639,7 +639,9 @@ __device__ __forceinline__ void integrate_chunk(const double *lds, const Consts 
 
 // Full forward solve for one lane.  Every thread of the workgroup must call it (chunk staging has barriers);
 // `resident` (workgroup-uniform): the single chunk is already staged, nothing is re-staged.
-template <bool DAMP, bool WANT_SSQ, bool WANT_ACC>
+// NUT: RK4 steps per trip of the TIGHT loop (integrate_multi); 16 where the kernel's registers allow it (one-parameter
+// sampler), 8 otherwise
+template <bool DAMP, bool WANT_SSQ, bool WANT_ACC, int NUT = RSF_TIGHT_UNROLL>
 __device__ __forceinline__ double solve(double *lds, const Consts &K, bool resident, bool active, double dc, double a,
                                         double b, double *acc_out, int64_t stride) {
   const Lane L = make_lane(dc, a, b, K);
@@ -653,7 +655,7 @@ __device__ __forceinline__ double solve(double *lds, const Consts &K, bool resid
   for (int k0 = 1; k0 < K.nout; k0 += K.kc) {
     const int kn = min(K.kc, K.nout - k0);
     if (!resident) stage_chunk(lds, K, k0, kn);
-    if (active) integrate_chunk<DAMP, WANT_SSQ, WANT_ACC>(lds, K, L, k0, kn, s, ssq, acc_out, stride);
+    if (active) integrate_chunk<DAMP, WANT_SSQ, WANT_ACC, NUT>(lds, K, L, k0, kn, s, ssq, acc_out, stride);
   }
   return ssq;
 }

@@ -360,7 +360,7 @@ __global__ void __launch_bounds__(kMaxBlock, MODE == DOP853 ? 1 : RSF_MIN_BLOCKS
     if (!resident || __any(inb)) {
       if constexpr (MODE == RK4_F32) ssqn = rsf::f32::solve32<DAMP, true, false>(lds32, K, resident, inb, qn[0], an, bn, nullptr, 0);
       else if constexpr (MODE == DOP853) ssqn = rsf::dp::solve<DAMP, true, false>(lds, K, resident, inb, qn[0], an, bn, nullptr, 0);
-      else ssqn = rsf::solve<DAMP, true, false>(lds, K, resident, inb, qn[0], an, bn, nullptr, 0);
+      else ssqn = rsf::solve<DAMP, true, false, (D == 1 ? 2 : 1) * RSF_TIGHT_UNROLL>(lds, K, resident, inb, qn[0], an, bn, nullptr, 0);
     }
     // ---- accept / reject, MCMC.py:327-333 ----
     bool accept = false;
