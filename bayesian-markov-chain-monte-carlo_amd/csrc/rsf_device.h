@@ -2,7 +2,8 @@
 //
 //   Philox4x32-10 counter RNG + Box-Muller normals + Marsaglia-Tsang gamma   (K3)
 //   rate-and-state friction RHS and the classical RK4 step, per lane          (K1 core)
-//     hot path: steps in pairs, transcendentals carried incrementally (rk4_fast / integrate_pairs)
+//     hot path: 8-16 steps per loop trip, transcendentals carried incrementally (rk4_fast / integrate_multi; the
+//               remainder in pairs, integrate_pairs)
 //     cold path: full log/exp evaluation (rk4_cold), taken when an increment leaves the series' guard region
 //   cooperative LDS staging of the chain-independent tables (loading V_l(t), observation)
 //
