@@ -130,6 +130,45 @@ def test_forward_is_scale_free_in_v_ref(gpu_engine, cpu_engine, oracle_mod, inte
         np.testing.assert_allclose(ag, a1 * 1.0e-6, rtol=1e-9, atol=1e-20)
 
 
+def test_forward_random_shapes(gpu_engine, cpu_engine, oracle_mod):
+    """Seeded sweep over series lengths and substeps (loop trips of 8, remainders in pairs, odd last step, samples
+    completing at any position of a trip, chunk boundaries) with lanes spread over all three tiers."""
+    rng = np.random.default_rng(2026)
+    for _ in range(24):
+        n = int(rng.integers(2, 260))
+        S = int(rng.choice([1, 1, 2, 3, 5, 8]))
+        damping = bool(rng.integers(0, 2))
+        m = _models(oracle_mod, n, S, damping, t1=0.1 * n)
+        for e in (gpu_engine, cpu_engine):
+            assert e.set_model(m, S) == m.nout
+        C = int(rng.integers(1, 140))
+        dc = np.exp(rng.uniform(np.log(30.0), np.log(9000.0), C))  # small Dc: NARROW / WIDE tiers and cold steps
+        data = rng.normal(0.0, 3e-3, m.nout)
+        sg, ag = gpu_engine.forward(dc, data=data, want_ssq=True, want_acc=True)
+        sc, ac = cpu_engine.forward(dc, data=data, want_ssq=True, want_acc=True)
+        fin = np.isfinite(sc)
+        assert (np.isfinite(sg) == fin).all(), (n, S)
+        if fin.any():
+            assert _traj_err(ag[:, fin], ac[:, fin]) < RTOL, (n, S, damping, C)
+            np.testing.assert_allclose(sg[fin], sc[fin], rtol=RTOL, err_msg=str((n, S, damping, C)))
+
+
+def test_sampler_random_shapes(gpu_engine, cpu_engine, oracle_mod):
+    """The same sweep through the sampler kernel (16 steps per loop trip in the one-parameter kernel)."""
+    rng = np.random.default_rng(2027)
+    for _ in range(10):
+        n = int(rng.integers(20, 400))
+        S = int(rng.choice([1, 1, 2, 3, 8]))
+        m = _models(oracle_mod, n, S, True, t1=0.1 * n)
+        for e in (gpu_engine, cpu_engine):
+            e.set_model(m, S)
+        data = synthetic_data(cpu_engine)
+        C = int(rng.integers(3, 200))
+        q0 = np.full((C, 1), float(rng.uniform(300.0, 3000.0)))
+        tg, tc = _run_pair(gpu_engine, cpu_engine, 5, C, q0, data, [0.0], [1e4], seed=int(rng.integers(1, 1000)), prior_len=3)
+        _assert_chains_match(tg, tc, min_same=0.97)
+
+
 def test_forward_edge_sizes(gpu_engine, cpu_engine, oracle_mod):
     m = _models(oracle_mod, 500)
     for e in (gpu_engine, cpu_engine):
