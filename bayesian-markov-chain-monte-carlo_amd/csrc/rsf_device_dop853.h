@@ -121,6 +121,57 @@ __device__ __forceinline__ double hinit(const Consts &K, const LaneD &L, double 
 }
 
 // one dop853 call (forward in time): y from x to xend; hc = carried step size (0 => HINIT).  false on failure.
+// the eleven inner stages of one step of size h from (x, y, k[0]; b0), evaluated incrementally; `bad`: some increment
+// left the series' range (the values of that lane are then not to be used)
+template <bool DAMP, bool TABULATED>
+__device__ __forceinline__ void stages_incr(const Consts &K, const LaneD &L, const double *tab, bool standard, double x, double h,
+                                            const double y[3], double (&k)[12][3], const Base &b0, bool &bad) {
+#pragma unroll
+  for (int st = 1; st < 12; ++st) {
+    double inc[3], ys[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      double s = 0.0;
+#pragma unroll
+      for (int j = 0; j < st; ++j)
+        if (RSF_DP_A[st - 1][j] != 0.0) s += RSF_DP_A[st - 1][j] * k[j][i];
+      inc[i] = h * s;
+      ys[i] = y[i] + inc[i];
+    }
+    const double vl = (TABULATED || standard) ? tab[st] : loading(K, st == 11 ? x + h : x + RSF_DP_C[st] * h);
+    friction_incr<DAMP>(K, L, vl, b0, inc[0], inc[1], ys, k[st], bad);
+  }
+}
+
+// 8th-order solution k5 and the error estimate of the step; returns err, and err ** (1/8) in fac11
+__device__ __forceinline__ double solution_and_error(double h, const double y[3], const double (&k)[12][3], double k5[3],
+                                                     double &fac11) {
+  double err = 0.0, err2 = 0.0;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    double s = 0.0, e3 = 0.0, e5 = 0.0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const double kj = k[RSF_DP_W_STAGE[j]][i];
+      s += RSF_DP_B[j] * kj;
+      e3 += RSF_DP_E3[j] * kj;
+      e5 += RSF_DP_E5[j] * kj;
+    }
+    k5[i] = y[i] + h * s;
+    // Step-size control: the error norm and the step-size factor only steer h (and the accept test err <= 1), so
+    // they use the kernel's reciprocal / log / exp (<= 4 ulp from the divisions and pow of the Fortran code, a fifth
+    // of their instructions); the solution itself (k5) is formed exactly as the reference forms it.
+    const double isk = fm::rcp(kAtol + kRtol * fmax(fabs(y[i]), fabs(k5[i])));
+    err2 += (e3 * isk) * (e3 * isk);
+    err += (e5 * isk) * (e5 * isk);
+  }
+  double deno = err + 0.01 * err2;
+  if (deno <= 0.0) deno = 1.0;
+  err = fabs(h) * err * sqrt(fm::rcp(3.0 * deno));
+  fac11 = err > 0.0 ? fm::exp(0.125 * fm::log(err)) : (err == 0.0 ? 0.0 : err);  // err ** (1/8); NaN stays NaN
+  return err;
+}
+
 // `tab` (LDS, 12 values) holds V_l at the stage times of the STANDARD step of this interval — the first step
 // clipped to h = xend - x, which is what every call after the first interval takes; x and xend are the
 // accumulated grid times shared by all lanes, so the host can tabulate them bit-exactly (rsf_set_model).
@@ -144,6 +195,26 @@ __device__ __forceinline__ bool call(const Consts &K, const LaneD &L, const doub
     friction<DAMP>(K, L, tab[0], y, k[0], b0);  // V_l(x): x is the interval's start time for every lane
   }
   if (h == 0.0) h = hinit<DAMP>(K, L, x, y, k[0], hmax);
+  // Fast path, the steady state of every call after the first interval: the carried step size reaches past xend for
+  // EVERY lane of the wave, so all take the tabulated step h = xend - x, and all accept it.  Two wave-uniform tests
+  // instead of the general loop's six per-lane branches (each of which a lone wave sits out for the latency of its
+  // compare).  Anything else — a lane that wants a smaller step, leaves the series' range or rejects — falls through
+  // to the general loop, which starts again from the untouched (x, y, k[0]).
+  if (__all(have_kf && (x + 1.01 * h - xend > 0.0) && !(0.1 * fabs(h) <= fabs(x) * uround))) {
+    const double hs = xend - x;
+    bool bad = false;
+    double fac11;
+    stages_incr<DAMP, true>(K, L, tab, true, x, hs, y, k, b0, bad);
+    const double err = solution_and_error(hs, y, k, k5, fac11);
+    if (__all(!bad && err <= 1.0)) {
+      friction<DAMP>(K, L, tab[11], k5, kf, bf);  // first-same-as-last, at xend: full evaluation
+#pragma unroll
+      for (int i = 0; i < 3; ++i) y[i] = k5[i];
+      x = x + hs;
+      hc = hs * fm::rcp(fmax(facc2, fmin(facc1, fac11 * (1.0 / safe))));
+      return true;
+    }
+  }
   for (int nstep = 0;; ) {
     if (nstep > 500) return false;
     if (0.1 * fabs(h) <= fabs(x) * uround) return false;
@@ -151,21 +222,7 @@ __device__ __forceinline__ bool call(const Consts &K, const LaneD &L, const doub
     const bool standard = last && nstep == 0;  // the tabulated step
     ++nstep;
     bool bad = false;
-#pragma unroll
-    for (int st = 1; st < 12; ++st) {
-      double inc[3];
-#pragma unroll
-      for (int i = 0; i < 3; ++i) {
-        double s = 0.0;
-#pragma unroll
-        for (int j = 0; j < st; ++j)
-          if (RSF_DP_A[st - 1][j] != 0.0) s += RSF_DP_A[st - 1][j] * k[j][i];
-        inc[i] = h * s;
-        ys[i] = y[i] + inc[i];
-      }
-      const double vl = standard ? tab[st] : loading(K, st == 11 ? x + h : x + RSF_DP_C[st] * h);
-      friction_incr<DAMP>(K, L, vl, b0, inc[0], inc[1], ys, k[st], bad);
-    }
+    stages_incr<DAMP, false>(K, L, tab, standard, x, h, y, k, b0, bad);
     if (__builtin_expect(__any(bad), 0)) {  // an increment outside the series' range: this step again, every stage in full
       if (bad) {
 #pragma unroll
@@ -183,29 +240,8 @@ __device__ __forceinline__ bool call(const Consts &K, const LaneD &L, const doub
         }
       }
     }
-    double err = 0.0, err2 = 0.0;
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      double s = 0.0, e3 = 0.0, e5 = 0.0;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const double kj = k[RSF_DP_W_STAGE[j]][i];
-        s += RSF_DP_B[j] * kj;
-        e3 += RSF_DP_E3[j] * kj;
-        e5 += RSF_DP_E5[j] * kj;
-      }
-      k5[i] = y[i] + h * s;
-      // Step-size control: the error norm and the step-size factor only steer h (and the accept test err <= 1), so
-      // they use the kernel's reciprocal / log / exp (<= 4 ulp from the divisions and pow of the Fortran code, a fifth
-      // of their instructions); the solution itself (k5) is formed exactly as before.
-      const double isk = fm::rcp(kAtol + kRtol * fmax(fabs(y[i]), fabs(k5[i])));
-      err2 += (e3 * isk) * (e3 * isk);
-      err += (e5 * isk) * (e5 * isk);
-    }
-    double deno = err + 0.01 * err2;
-    if (deno <= 0.0) deno = 1.0;
-    err = fabs(h) * err * sqrt(fm::rcp(3.0 * deno));
-    const double fac11 = err > 0.0 ? fm::exp(0.125 * fm::log(err)) : (err == 0.0 ? 0.0 : err);  // err ** (1/8); NaN stays NaN
+    double fac11;
+    const double err = solution_and_error(h, y, k, k5, fac11);
     double hnew = h * fm::rcp(fmax(facc2, fmin(facc1, fac11 * (1.0 / safe))));
     if (err <= 1.0) {
       friction<DAMP>(K, L, standard ? tab[11] : loading(K, x + h), k5, k[0], b0);  // first-same-as-last, at x + h: full
