@@ -69,28 +69,40 @@ __device__ __forceinline__ void friction(const Consts &K, const LaneD &L, double
 // — ONE test per step: a branch per stage would stall a lone wave for the latency of its compare eleven times per
 // step.  A DOP853 step spans one output interval, so its stage increments are those of an RK4 step: the full log/exp
 // is needed only at the step's end points.
-template <bool DAMP>
+// SHORT: the series lengths and thresholds of rsf_device.h's TIGHT tier (log1p to rho^2/2 inside |rho| < 2^-20, expm1 to
+// dlt^5/120 inside |dlt| < 2^-9) — what the steady-state fast path of call() tries first.
+template <bool DAMP, bool SHORT>
 __device__ __forceinline__ void friction_incr(const Consts &K, const LaneD &L, double vl, const Base &b0, double dmu, double dth,
                                               const double ys[3], double f[3], bool &bad) {
   const double rho = dth * b0.rth;
-  double p = -1.0 / 6.0;
-  p = __builtin_fma(p, rho, 1.0 / 5.0);
-  p = __builtin_fma(p, rho, -1.0 / 4.0);
-  p = __builtin_fma(p, rho, 1.0 / 3.0);
-  p = __builtin_fma(p, rho, -0.5);
-  p = __builtin_fma(p, rho, 1.0);
+  double p;
+  if (SHORT) {
+    p = __builtin_fma(rho, -0.5, 1.0);
+  } else {
+    p = -1.0 / 6.0;
+    p = __builtin_fma(p, rho, 1.0 / 5.0);
+    p = __builtin_fma(p, rho, -1.0 / 4.0);
+    p = __builtin_fma(p, rho, 1.0 / 3.0);
+    p = __builtin_fma(p, rho, -0.5);
+    p = __builtin_fma(p, rho, 1.0);
+  }
   const double dlt = L.inv_a * __builtin_fma(-L.b, p * rho, dmu);
-  bad = bad || !(__builtin_fabs(rho) < 0x1.0p-9 && __builtin_fabs(dlt) < 0x1.0p-6);
-  double e = 1.0 / 5040.0;
-  e = __builtin_fma(e, dlt, 1.0 / 720.0);
-  e = __builtin_fma(e, dlt, 1.0 / 120.0);
+  bad = bad || !(__builtin_fabs(rho) < (SHORT ? 0x1.0p-20 : 0x1.0p-9) && __builtin_fabs(dlt) < (SHORT ? 0x1.0p-9 : 0x1.0p-6));
+  double e;
+  if (SHORT) {
+    e = 1.0 / 120.0;
+  } else {
+    e = 1.0 / 5040.0;
+    e = __builtin_fma(e, dlt, 1.0 / 720.0);
+    e = __builtin_fma(e, dlt, 1.0 / 120.0);
+  }
   e = __builtin_fma(e, dlt, 1.0 / 24.0);
   e = __builtin_fma(e, dlt, 1.0 / 6.0);
   e = __builtin_fma(e, dlt, 0.5);
   e = __builtin_fma(e, dlt, 1.0);
   const double v = __builtin_fma(b0.v * dlt, e, b0.v);
   double rth = __builtin_fma(b0.rth, __builtin_fma(rho, rho, -rho), b0.rth);
-  rth = __builtin_fma(rth, __builtin_fma(-ys[1], rth, 1.0), rth);
+  if (!SHORT) rth = __builtin_fma(rth, __builtin_fma(-ys[1], rth, 1.0), rth);  // (|rho| < 2^-20: the series is exact to rounding)
   friction_tail<DAMP>(K, L, vl, v, rth, ys[1], f);
 }
 
@@ -122,7 +134,8 @@ __device__ __forceinline__ double hinit(const Consts &K, const LaneD &L, double 
 
 // one dop853 call (forward in time): y from x to xend; hc = carried step size (0 => HINIT).  false on failure.
 // the eleven inner stages of one step of size h from (x, y, k[0]; b0), evaluated incrementally; `bad`: some increment
-// left the series' range (the values of that lane are then not to be used)
+// left the series' range (the values of that lane are then not to be used).  TABULATED = the fast path of call(): the
+// loading table and the short series.
 template <bool DAMP, bool TABULATED>
 __device__ __forceinline__ void stages_incr(const Consts &K, const LaneD &L, const double *tab, bool standard, double x, double h,
                                             const double y[3], double (&k)[12][3], const Base &b0, bool &bad) {
@@ -139,7 +152,7 @@ __device__ __forceinline__ void stages_incr(const Consts &K, const LaneD &L, con
       ys[i] = y[i] + inc[i];
     }
     const double vl = (TABULATED || standard) ? tab[st] : loading(K, st == 11 ? x + h : x + RSF_DP_C[st] * h);
-    friction_incr<DAMP>(K, L, vl, b0, inc[0], inc[1], ys, k[st], bad);
+    friction_incr<DAMP, TABULATED>(K, L, vl, b0, inc[0], inc[1], ys, k[st], bad);
   }
 }
 
