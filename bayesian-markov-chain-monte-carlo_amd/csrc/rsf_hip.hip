@@ -94,7 +94,7 @@ forward_kernel(Consts K, int64_t n, const double *__restrict__ dc, const double 
       ssq = rsf::dp::solve<DAMP, WANT_SSQ, WANT_ACC>(lds, K, resident, active, dci, ai, bi, acc_i, n);
     } else {
       if (resident) rsf::stage_chunk(lds, K, 1, K.nout - 1);
-      ssq = rsf::solve<DAMP, WANT_SSQ, WANT_ACC>(lds, K, resident, active, dci, ai, bi, acc_i, n);
+      ssq = rsf::solve<DAMP, WANT_SSQ, WANT_ACC, 2 * RSF_TIGHT_UNROLL>(lds, K, resident, active, dci, ai, bi, acc_i, n);
     }
   }
   if (WANT_SSQ && active) ssq_out[i] = ssq;
