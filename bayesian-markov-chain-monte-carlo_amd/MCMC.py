@@ -17,7 +17,12 @@ import warnings
 
 import numpy as np
 
-from ._abi import ADAPT_MODES
+if __package__:
+    from ._abi import ADAPT_MODES
+    from .engine import Engine
+else:  # flat layout: this directory on sys.path, the reference's own import style (main.py:44-46)
+    from _abi import ADAPT_MODES
+    from engine import Engine
 
 
 class PosteriorPool:
@@ -181,8 +186,6 @@ class MCMC:
         uniformly in `jitter=(lo, hi)` with a NumPy generator seeded by `seed` and keyed by
         global chain id.  Returns a PosteriorPool of the post-burn-in draws; `thin=k` keeps every k-th kept draw
         (the pool of a long multi-GPU run need not hold, or all-gather, every iteration: SURVEY §8e)."""
-        from .engine import Engine
-
         if int(thin) < 1:
             raise ValueError("thin must be >= 1")
         thin = int(thin)

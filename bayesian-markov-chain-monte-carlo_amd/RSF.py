@@ -13,8 +13,14 @@ import warnings
 
 import numpy as np
 
-from . import json_save_load
-from .MCMC import MCMC
+if __package__:
+    from . import json_save_load
+    from .engine import Engine
+    from .MCMC import MCMC, PosteriorPool
+else:  # flat layout: this directory on sys.path, the reference's own import style (main.py:44-46)
+    import json_save_load
+    from engine import Engine
+    from MCMC import MCMC, PosteriorPool
 
 
 def measure_execution_time(func):
@@ -127,9 +133,6 @@ class RSF:
         """Additive throughput path: the whole dc_list sweep as ONE launch per block of iterations — every
         true Dc is an observation group with `chains_per_dc` independent chains (Philox variates on device).
         Returns {dc: PosteriorPool} of the post-burn-in draws (nburn = int(nsamples/2) like MCMC)."""
-        from .engine import Engine
-        from .MCMC import PosteriorPool
-
         n, G = self.model.num_tsteps, len(self.dc_list)
         data = np.ascontiguousarray(np.asarray(self.data, dtype=np.float64).reshape(G, n))
         probe = MCMC(self.model, data[0], self.dc_list[0], self.qpriors, self.qstart, nsamples=nsamples)

@@ -10,6 +10,11 @@ Additive surface: `substeps`, `precision`, `integrator`, `evaluate_batch(dc, a=N
 """
 import numpy as np
 
+if __package__:
+    from .engine import Engine
+else:  # flat layout: this directory on sys.path, the reference's own import style (main.py:44-46)
+    from engine import Engine
+
 # RateStateModel.py:5-11
 A = 0.011
 B = 0.014
@@ -52,8 +57,6 @@ class RateStateModel:
 
     def engine(self):
         """Host-memory Engine bound to the HIP library, re-armed when an attribute changed."""
-        from .engine import Engine
-
         if self._engine is None:
             self._engine = Engine(mem="host")
         key = self._model_key()

@@ -272,6 +272,7 @@ struct McmcArgs {
   double gd, gc;  // Marsaglia-Tsang constants of Gamma(shape): d = shape - 1/3, c = 1/sqrt(9 d)
   double lo[RSF_MAX_PARAMS], hi[RSF_MAX_PARAMS];
   int32_t adapt_mode, adapt_interval;
+  double dict_scale;  // 2.38^2 / len(qpriors.keys()), MCMC.py:200 (reference_dict mode)
   double *q, *ssq, *std2, *V;           // per-chain state
   double *wref, *wsum, *wsq;            // adaptation window (shifted sums)
   int32_t *wn;
@@ -412,8 +413,8 @@ __global__ void __launch_bounds__(kMaxBlock, MODE == DOP853 ? 1 : RSF_MIN_BLOCKS
           const double nn = (double)wn;
           double Vn[D * D], Ln[D * D];
           if (A.adapt_mode == RSF_ADAPT_REFERENCE_DICT) {
-            // d := len(qpriors.keys()) = 2, and the Cholesky FACTOR becomes the next covariance
-            Vn[0] = 2.38 * 2.38 / 2.0 * ((wq[0] - ws[0] * ws[0] / nn) / (nn - 1.0));
+            // d := len(qpriors.keys()) (2 for {1: lo, 2: hi}), and the Cholesky FACTOR becomes the next covariance
+            Vn[0] = A.dict_scale * ((wq[0] - ws[0] * ws[0] / nn) / (nn - 1.0));
             if (rsf::chol_lower<1>(Vn, Ln)) V[0] = Ln[0];
           } else {
 #pragma unroll
@@ -873,6 +874,7 @@ int run_mcmc(rsf_ctx *c, int64_t n_iters, const double *z, const double *u, cons
   A.gd = A.shape - 1.0 / 3.0; A.gc = 1.0 / std::sqrt(9.0 * A.gd);
   for (int p = 0; p < RSF_MAX_PARAMS; ++p) { A.lo[p] = c->mc.lo[p]; A.hi[p] = c->mc.hi[p]; }
   A.adapt_mode = c->mc.adapt_mode; A.adapt_interval = c->mc.adapt_interval > 0 ? c->mc.adapt_interval : 1;
+  A.dict_scale = 2.38 * 2.38 / (double)(c->mc.prior_len > 0 ? c->mc.prior_len : 2);
   A.q = (double *)c->q.p; A.ssq = (double *)c->ssq.p; A.std2 = (double *)c->std2.p; A.V = (double *)c->V.p;
   A.wref = (double *)c->wref.p; A.wsum = (double *)c->wsum.p; A.wsq = (double *)c->wsq.p; A.wn = (int32_t *)c->wn.p;
   A.stats = (unsigned long long *)c->stats.p;

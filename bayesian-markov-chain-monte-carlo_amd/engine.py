@@ -12,7 +12,10 @@ import ctypes
 
 import numpy as np
 
-from . import _abi
+if __package__:
+    from . import _abi
+else:  # flat layout: this directory on sys.path, the reference's own import style (main.py:44-46)
+    import _abi
 
 
 def _model_struct(model, substeps):

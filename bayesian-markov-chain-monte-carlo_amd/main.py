@@ -3,15 +3,12 @@ Entry script, same surface as the reference's main.py (:44-451): module constant
 setup_problem(), perform_inference(problem, data_format, nsamples), main().
 Run as `python main.py` from this directory (like the reference) or import it from the package.
 """
-if __package__ in (None, ""):  # executed as a script: load the package through its alias module
-    import os
-    import sys
-
-    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    from bayesian_markov_chain_monte_carlo_amd import RSF, RateStateModel
-else:
+if __package__:
     from .RateStateModel import RateStateModel
     from .RSF import RSF
+else:  # `python main.py` from this directory, or this directory on sys.path: the reference's flat imports (main.py:44-46)
+    from RSF import RSF
+    from RateStateModel import RateStateModel
 
 # main.py:50-56
 NUMBER_SLIP_VALUES = 5

@@ -2,20 +2,27 @@
 """
 bench.py — headline metric of the MCMC-over-ODE hot path on MI355X.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg1|cfg2]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg2|cfg1]
 
 One "step" = one launch of the fused MCMC kernel: `iters_per_step` Metropolis proposals for every
 chain of this GPU, each proposal costing one rate-and-state RK4 forward solve of `nsteps` output
 intervals.  Inputs (observation, loading table, chain state) are resident in HBM before the timed
 region.  metric = chains × proposals × nsteps / wall seconds, whole job (all ranks).
 
-N > 1: launched by torch.distributed.run, one rank per GPU; chains shard by global id with no
-data-path collective (weak scaling: per-GPU chains fixed); after the timed region the post-burn
-sample block is pooled with ONE RCCL all-gather, timed separately.
+Default workload: BASELINE.json configs[2] (262 144 chains x nsteps 2000, fp64) — the largest configuration that
+fits one GPU; the configs[1] shape is measured in the same process afterwards and carried under "also".
+
+N > 1: one rank per GPU under torch.distributed.run.  `python bench.py --gpus N` without that launcher starts it
+itself: the parent touches no GPU API, spawns `python -m torch.distributed.run --nproc-per-node N bench.py ...`
+as a fresh child, relays rank 0's JSON line and exits with the child's status.  Chains shard by global id with no
+data-path collective (weak scaling: per-GPU chains fixed); after the timed region the post-burn sample block is
+pooled with ONE RCCL all-gather, timed separately.
 
 Also printed in the same JSON line:
-  roofline      HBM view the metric names (algorithmic 16 B per chain-proposal) + the fp64-VALU
-                view that actually bounds this kernel (152 nominal flops per RK4 step);
+  roofline      the bound that binds this kernel: fp64 VALU issue (152 nominal flops per RK4 step against the
+                78.6 TFLOP/s fp64-vector peak), with the instruction count and pipe occupancy the PMC profile of
+                the same launch shape gave; roofline_hbm is the HBM view the metric names (algorithmic 16 B per
+                chain-proposal), O(1e-3) of peak by construction;
   cpu_baseline  the CPU restatement (oracle/, OpenMP over chains) timed on this host's cores on a
                 bounded sample of the same workload (rank 0, N = 1 only);
   reference_scheme  the same workload integrated with the reference's own DOP853 scheme (short side run, N = 1 only).
@@ -98,6 +105,10 @@ def cpu_baseline(model, data, target_s=12.0):
         e.mcmc_run(40, traces=False)
         one_core = 8 * 40 * nsteps / (time.perf_counter() - t0)
     return dict(value=chains * iters * nsteps / wall, unit="ODE-steps*chains/s", cores=cores, kind="port", single_thread_value=one_core,
+                cpu_model=cpu_model_name(),
+                reference_python={"value": 2.7e3, "unit": "ODE-steps*chains/s", "cores": 1,
+                                  "where": "the reference's own Python/SciPy path, measured in the survey container (BASELINE.md §3); "
+                                           "it cannot travel to this box, so this figure is quoted, not re-measured here"},
                 sample=f"{chains} chains x {iters} proposals x nsteps {nsteps} ({nout - 1} RK4 steps each), "
                        f"oracle/librsf_oracle.so with OpenMP over chains, {wall:.1f} s")
 
@@ -160,19 +171,112 @@ def abi_pool_allgather(eng, local, expected_pool, rdist, timeout_s=90.0):
     return dict(res)
 
 
+def cpu_model_name():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.lower().startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def self_launch(n_gpus):
+    """`python bench.py --gpus N` without a launcher: start N fresh ranks under torch.distributed.run as a CHILD process
+    (this parent has touched no GPU API and never execs), relay rank 0's JSON line, exit with the child's status."""
+    import socket
+    import subprocess
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    proc = subprocess.run(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    lines = [l for l in proc.stdout.splitlines() if l.startswith('{"metric"')]
+    if lines:
+        print(lines[-1], flush=True)
+    if proc.returncode != 0 or not lines:
+        sys.stderr.write(f"bench.py: child ranks exited with status {proc.returncode}"
+                         f"{'' if lines else ' and printed no result line'}\n")
+        sys.exit(proc.returncode or 1)
+    sys.exit(0)
+
+
+def time_sampler(pkg, model, data, C, ips, steps, warmup, rank, barrier):
+    """W untimed + K timed launches of the fused sampler (ips proposals per chain each) on `C` chains of this rank.
+    → (wall seconds of the K launches, mean kernel ms from HIP events on the launch stream, stats, engine, traces)."""
+    import torch
+
+    eng = pkg.Engine(mem="device")
+    nout = eng.set_model(model, 1)
+    q0 = torch.full((C, 1), 1000.0, dtype=torch.float64, device="cuda")
+    eng.mcmc_init(q0, data, [0.0], [1.0e4], seed=2025, chain_offset=rank * C, prior_len=3, adapt_mode="none")
+    traces = (torch.empty((ips, C, 1), dtype=torch.float64, device="cuda"),
+              torch.empty((ips, C), dtype=torch.float64, device="cuda"), None)
+    for _ in range(warmup):
+        eng.mcmc_run(ips, out=traces)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    barrier()
+    t0 = time.perf_counter()
+    for a, b in ev:          # the engine launches on torch's current stream, so these events bracket the kernel
+        a.record()
+        eng.mcmc_run(ips, out=traces)
+        b.record()
+    barrier()
+    wall = time.perf_counter() - t0
+    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    return wall, kernel_ms, eng.stats(), eng, traces, nout
+
+
+def roofline_views(workload, custom, C, ips, nout, stats, kernel_ms):
+    """The two roofline views of one launch of the sampler kernel."""
+    evaluated = stats["evaluated"] / max(1, stats["iters_done"] * C)
+    per_launch_props = C * ips
+    rk4_steps_per_launch = per_launch_props * (nout - 1) * evaluated
+    hbm_gbs = BYTES_PER_PROPOSAL * per_launch_props / (kernel_ms * 1e-3) / 1e9
+    tflops = FLOPS_PER_RK4_STEP * rk4_steps_per_launch / (kernel_ms * 1e-3) / 1e12
+    pmc = {}
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(path) and not custom:
+        with open(path) as f:
+            t = json.load(f)
+        if t.get(workload + "_iters_per_step") == ips:   # PMC figures belong to this launch shape
+            pmc = {"traffic": t.get(workload), "valu_insts_per_rk4_step": t.get(workload + "_valu_per_rk4_step"),
+                   "pipe_busy": t.get(workload + "_pipe_busy"),
+                   "pmc_source": f"rocprofv3 PMC passes of this launch shape, {t.get(workload + '_source')} — stored, not measured in this run"}
+    valu = {"bound": "valu_fp64", "achieved": tflops, "peak": PEAK_FP64_VALU_TFLOPS, "unit": "TFLOP/s",
+            "frac": tflops / PEAK_FP64_VALU_TFLOPS, "traffic": pmc.get("traffic"),
+            "kernel": "mcmc_kernel<1,damp,philox,RK4>", "kernel_ms": kernel_ms,
+            "flops_per_rk4_step": FLOPS_PER_RK4_STEP, "rk4_steps_per_s": rk4_steps_per_launch / (kernel_ms * 1e-3),
+            "valu_insts_per_rk4_step": pmc.get("valu_insts_per_rk4_step"), "pipe_busy": pmc.get("pipe_busy"),
+            "pmc_source": pmc.get("pmc_source"),
+            "note": "fp64 VALU issue binds (no MFMA: elementwise ODE recurrence); peak = 256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz; "
+                    "pipe_busy = 4 cycles x SQ_INSTS_VALU / SIMDs / GRBM_GUI_ACTIVE is the utilisation figure, frac the nominal-flop one"}
+    hbm = {"bound": "hbm", "achieved": hbm_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": hbm_gbs / PEAK_HBM_GBS,
+           "traffic": pmc.get("traffic"), "algorithmic_bytes_per_launch": BYTES_PER_PROPOSAL * per_launch_props,
+           "note": "HBM view the metric names: 16 B written per chain-proposal; arithmetic intensity ~4750 flop/B, not the binding bound"}
+    return valu, hbm, evaluated
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="cfg1", choices=sorted(WORKLOADS))
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
     ap.add_argument("--chains", type=int, default=0, help="chains per GPU (default: the workload's)")
     ap.add_argument("--nsteps", type=int, default=0)
     ap.add_argument("--iters-per-step", type=int, default=100, help="proposals per chain per launch (SURVEY §8d: 100)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-also", action="store_true", help="skip the secondary configs[1] measurement")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend for N > 1 (nccl = RCCL; gloo only to rehearse the N > 1 path on one GPU)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args.gpus)  # does not return
 
     # stdout carries exactly ONE line, the result: everything any library prints meanwhile (RCCL's version banner at the
     # first communicator, for one) goes to stderr — file descriptor 1 is pointed at stderr until the line is written
@@ -188,25 +292,18 @@ def main():
 
     world = int(os.environ.get("WORLD_SIZE", 1))
     rank = int(os.environ.get("RANK", 0))
+    if world != max(1, args.gpus):
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU")
     if world > 1:
         rank, world = rdist.init_process_group(args.backend)
-    elif args.gpus > 1:
-        raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
     torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", 0)) % torch.cuda.device_count())
     coll_dev = "cuda" if args.backend == "nccl" else "cpu"  # gloo rehearsal moves the collectives' tensors to the host
 
     wl = WORKLOADS[args.workload]
+    custom = bool(args.chains or args.nsteps)
     C = args.chains or wl["chains"]          # per GPU: weak scaling
     nsteps = args.nsteps or wl["nsteps"]
     ips = args.iters_per_step
-
-    model, data = synthetic_problem(nsteps)
-    eng = pkg.Engine(mem="device")
-    nout = eng.set_model(model, 1)
-    q0 = torch.full((C, 1), 1000.0, dtype=torch.float64, device="cuda")
-    eng.mcmc_init(q0, data, [0.0], [1.0e4], seed=2025, chain_offset=rank * C, prior_len=3, adapt_mode="none")
-    traces = (torch.empty((ips, C, 1), dtype=torch.float64, device="cuda"),
-              torch.empty((ips, C), dtype=torch.float64, device="cuda"), None)
 
     def barrier():
         torch.cuda.synchronize()
@@ -214,19 +311,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        eng.mcmc_run(ips, out=traces)
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    barrier()
-    t0 = time.perf_counter()
-    for a, b in ev:          # the engine launches on torch's current stream, so these events bracket the kernel
-        a.record()
-        eng.mcmc_run(ips, out=traces)
-        b.record()
-    barrier()
-    wall = time.perf_counter() - t0
-    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
-    stats = eng.stats()
+    model, data = synthetic_problem(nsteps)
+    wall, kernel_ms, stats, eng, traces, nout = time_sampler(pkg, model, data, C, ips, args.steps, args.warmup, rank, barrier)
 
     if world > 1:
         t = torch.tensor([wall], dtype=torch.float64, device=coll_dev)
@@ -244,50 +330,56 @@ def main():
         allgather_ms = abi_pool = None
 
     if rank == 0:
-        proposals = world * C * ips * args.steps
-        value = proposals * nsteps / wall
-        per_launch_props = C * ips
-        rk4_steps_per_launch = per_launch_props * (nout - 1) * stats["evaluated"] / max(1, stats["iters_done"] * C)
-        hbm_gbs = BYTES_PER_PROPOSAL * per_launch_props / (kernel_ms * 1e-3) / 1e9
-        tflops = FLOPS_PER_RK4_STEP * rk4_steps_per_launch / (kernel_ms * 1e-3) / 1e12
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc):
-            with open(pmc) as f:
-                t = json.load(f)
-            if t.get(args.workload + "_iters_per_step") == ips and not (args.chains or args.nsteps):
-                traffic = t.get(args.workload)   # PMC bytes per launch, measured for this launch shape
+        value = world * C * ips * args.steps * nsteps / wall
+        valu, hbm, evaluated = roofline_views(args.workload, custom, C, ips, nout, stats, kernel_ms)
         out = {
             "metric": "ode_steps_x_chains_per_sec", "value": value, "unit": "ODE-steps*chains/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": wl["desc"] if not (args.chains or args.nsteps) else f"custom: {C} chains x nsteps {nsteps}, fp64",
+            "config": {"workload": wl["desc"] if not custom else f"custom: {C} chains x nsteps {nsteps}, fp64",
                        "chains_per_gpu": C, "nsteps": nsteps, "rk4_substeps": 1, "proposals_per_chain_per_step": ips,
                        "n_params": 1, "adapt_mode": "none", "parallelism": f"chains sharded over {world} GPU(s), no data-path collective",
-                       "evaluated_fraction": stats["evaluated"] / max(1, stats["iters_done"] * C),
+                       "evaluated_fraction": evaluated,
                        "acceptance": stats["accepted"] / max(1, stats["iters_done"] * C)},
-            "roofline": {"bound": "hbm", "achieved": hbm_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": hbm_gbs / PEAK_HBM_GBS,
-                         "traffic": traffic, "kernel": "mcmc_kernel<1,damp,philox>", "kernel_ms": kernel_ms,
-                         "note": "HBM view as the metric asks; this kernel is fp64-VALU bound (see roofline_valu)"},
-            "roofline_valu": {"bound": "valu_fp64", "achieved": tflops, "peak": PEAK_FP64_VALU_TFLOPS, "unit": "TFLOP/s",
-                              "frac": tflops / PEAK_FP64_VALU_TFLOPS, "flops_per_rk4_step": FLOPS_PER_RK4_STEP,
-                              "rk4_steps_per_s": rk4_steps_per_launch / (kernel_ms * 1e-3)},
+            "roofline": valu, "roofline_hbm": hbm,
         }
         if allgather_ms is not None:
             out["pool_allgather_ms"] = allgather_ms
         if abi_pool is not None:
             out["pool_allgather_c_abi"] = abi_pool
-        if world == 1 and not args.no_cpu_baseline:
+    if world == 1:
+        eng.close()
+        del traces
+        torch.cuda.empty_cache()
+        if not args.no_also and not custom:
+            # the other single-GPU BASELINE configuration, same process, same method (secondary figure)
+            other = "cfg1" if args.workload == "cfg2" else "cfg2"
+            wo = WORKLOADS[other]
+            k = max(3, min(args.steps, 10))
+            model_o, data_o = synthetic_problem(wo["nsteps"])
+            w_o, kms_o, st_o, eng_o, tr_o, nout_o = time_sampler(pkg, model_o, data_o, wo["chains"], ips, k, 2, 0, barrier)
+            valu_o, _, _ = roofline_views(other, False, wo["chains"], ips, nout_o, st_o, kms_o)
+            out["also"] = {other: {"workload": wo["desc"], "value": wo["chains"] * ips * k * wo["nsteps"] / w_o,
+                                   "unit": "ODE-steps*chains/s", "steps": k, "ms_per_step": w_o / k * 1e3,
+                                   "roofline": {kk: valu_o[kk] for kk in ("bound", "achieved", "peak", "unit", "frac", "kernel_ms",
+                                                                          "valu_insts_per_rk4_step", "pipe_busy", "traffic")}}}
+            eng_o.close()
+            del tr_o
+            torch.cuda.empty_cache()
+        if not args.no_cpu_baseline:
             out["reference_scheme"] = reference_scheme_rate(model, data, C, nsteps)
             out["cpu_baseline"] = cpu_baseline(model, data)
+    if rank == 0:
         sys.stdout.flush()
         os.dup2(result_fd, 1)
         print(json.dumps(out), flush=True)
         os.dup2(2, 1)
     if abi_pool is not None and abi_pool.get("status") == "timeout":
-        os._exit(0)  # a rank stuck inside a collective cannot be torn down cleanly; the result line is out
-    eng.close()
+        # a rank stuck inside a collective cannot be torn down cleanly; the result line is out, but a hung collective is
+        # a failure of the run, not a success: non-zero status
+        os._exit(3)
     if world > 1:
+        eng.close()
         dist.destroy_process_group()
 
 

@@ -68,7 +68,7 @@ extern "C" {
 
 /* rsf_mcmc_config.adapt_mode (MCMC.py:162-204, 523-527) */
 #define RSF_ADAPT_NONE 0           /* list prior: adaptation raises and is swallowed => never adapts */
-#define RSF_ADAPT_REFERENCE_DICT 1 /* dict prior: V <- chol(2.38^2/2 * cov(window)), then used AS covariance */
+#define RSF_ADAPT_REFERENCE_DICT 1 /* dict prior: V <- chol(2.38^2/prior_len * cov(window)), then used AS covariance */
 #define RSF_ADAPT_AM 2             /* corrected adaptive Metropolis: V <- 2.38^2/d * cov(window) */
 
 #define RSF_MAX_PARAMS 3
@@ -108,7 +108,8 @@ typedef struct rsf_mcmc_config {
   int64_t chain_offset;   /* global id of local chain 0 (multi-GPU sharding; keys the RNG) */
   uint64_t seed;          /* Philox4x32-10 key */
   double n0;              /* MCMC.n0 = 0.01, MCMC.py:97 */
-  int32_t prior_len;      /* len(qpriors) quirk in std2[0] divisor, MCMC.py:261: 3 list / 2 dict; 0 => d */
+  int32_t prior_len;      /* len(qpriors): the std2[0] divisor nout - len(qpriors), MCMC.py:261 (3 list / 2 dict; 0 => d),
+                             and reference_dict's scale 2.38^2/len(qpriors.keys()), MCMC.py:200 (0 => 2) */
   int32_t adapt_mode;     /* RSF_ADAPT_* */
   int32_t adapt_interval; /* MCMC.adapt_interval, default 10 */
   int32_t n_groups;       /* observation series: 0/1 = one shared by all chains; G > 1 = data is [G][nout] and

@@ -240,12 +240,63 @@ def config1_run():
                        kept=int(q.shape[1]), cpu="build container, 1 core"), f, indent=1)
 
 
+def rsf_driver_vectors(nsamples=30, seed_data=7, seed_chains=11):
+    """A13 / A14: the reference's RSF.generate_time_series() (RSF.py:355-371) for a 3-value dc_list under
+    np.random.seed, then — from ONE further seed, sequentially in dc_list order like RSF.inference's loop
+    (RSF.py:1042-1044) — MCMC(model, data[i*N:(i+1)*N], dc, qpriors, qstart, nsamples=...).sample(False) per Dc
+    (the slice and constructor arguments of RSF.perform_sampling_and_plotting, RSF.py:874-894).  MCMC is driven
+    directly because RSF.inference cannot run as shipped (its JSON helpers are shadowed by the MySQL ones and
+    sample(True) needs ffmpeg)."""
+    from RSF import RSF
+
+    kw = dict(number_slip_values=3, lowest_slip_value=500.0, largest_slip_value=2500.0, qstart=1000.0,
+              qpriors=["Uniform", 0.0, 10000.0])
+    problem = RSF(**kw)
+    problem.model = RateStateModel(number_time_steps=500)
+    np.random.seed(seed_data)
+    data = problem.generate_time_series()
+    n = problem.model.num_tsteps
+    out = dict(data=data, dc_list=np.asarray(problem.dc_list, dtype=np.float64))
+    np.random.seed(seed_chains)
+    for i, dc in enumerate(problem.dc_list):
+        mc = MCMC(problem.model, data[i * n:(i + 1) * n], dc, problem.qpriors, problem.qstart, lstm_model=None, nsamples=nsamples)
+        with quiet():
+            q = mc.sample(False)
+        out[f"qparams_{i}"], out[f"std2_{i}"] = q, np.asarray(mc.std2, dtype=np.float64).ravel()
+    np.savez_compressed(os.path.join(OUT, "rsf_driver.npz"), **out)
+    with open(os.path.join(OUT, "rsf_driver.json"), "w") as f:
+        json.dump(dict(source="RSF.generate_time_series (RSF.py:355-371) + per-Dc MCMC.sample(False) on data[i*N:(i+1)*N] (RSF.py:874-894)",
+                       rsf_kwargs=kw, number_time_steps=500, nsamples=nsamples, seed_data=seed_data, seed_chains=seed_chains,
+                       note="np.random.seed(seed_data) before generate_time_series(); np.random.seed(seed_chains) once before the "
+                            "sequential per-Dc chains"), f, indent=1)
+
+
+def json_fixtures():
+    """Files written by the REFERENCE's json_save_load.save_object (json_save_load.py:37-39, 128-130): an ndarray and a
+    dict of ndarrays (nested, 2-D and scalar members) — fixtures for the repo's load_object / byte-equal save_object."""
+    import json_save_load as ref_json
+
+    rng = np.random.default_rng(3)
+    vec = rng.standard_normal(12) * 1e-3
+    obj = {"acc": vec, "grid": np.arange(6, dtype=np.float64).reshape(2, 3), "meta": {"dc": 1000.0, "n": 12, "tags": ["a", "b"]},
+           "ints": np.arange(4)}
+    ref_json.save_object(vec, os.path.join(OUT, "ref_written_array.json"))
+    ref_json.save_object(obj, os.path.join(OUT, "ref_written_dict.json"))
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--long", action="store_true")
     ap.add_argument("--only-nondefault", action="store_true", help="write only forward_nondefault.* (added later)")
+    ap.add_argument("--only-round2", action="store_true", help="write only the vectors added in round 2 (rsf_driver.*, "
+                    "ref_written_*.json, replay_dict3.*)")
     args = ap.parse_args()
     os.makedirs(OUT, exist_ok=True)
+    rsf_driver_vectors()
+    json_fixtures()
+    replay_vectors("dict3", {0: "Uniform", 1: 0.0, 2: 10000.0}, 1000.0, 120)
+    if args.only_round2:
+        sys.exit(0)
     nondefault_vectors()
     if args.only_nondefault:
         sys.exit(0)

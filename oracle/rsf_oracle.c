@@ -617,8 +617,8 @@ static void run_chain(rsf_ctx *c, int64_t i, int64_t n_iters, const double *zs, 
             for (int r = 0; r < d; ++r)
               cov[p * d + r] = (wq[p * d + r] - ws[p] * ws[r] / nn) / (nn - 1.0); /* np.cov, ddof=1 */
           if (mc->adapt_mode == RSF_ADAPT_REFERENCE_DICT) {
-            /* d := len(qpriors.keys()) = 2; the Cholesky FACTOR becomes the next covariance */
-            Vn[0] = 2.38 * 2.38 / 2.0 * cov[0];
+            /* d := len(qpriors.keys()) (MCMC.py:200; 2 for {1: lo, 2: hi}); the Cholesky FACTOR becomes the next covariance */
+            Vn[0] = 2.38 * 2.38 / (double)(mc->prior_len > 0 ? mc->prior_len : 2) * cov[0];
             if (chol_lower(Vn, 1, Ln)) V[0] = Ln[0];
           } else {
             for (int e = 0; e < d * d; ++e) Vn[e] = 2.38 * 2.38 / (double)d * cov[e];

@@ -177,3 +177,59 @@ def test_bench_c_abi_pool_exchange_helper(pkg):
         assert res["status"] == "ok" and res["equals_torch_pool"] is True, res
     finally:
         dist.destroy_process_group()
+
+
+def test_bench_self_launches_ranks(tmp_path):
+    """`python bench.py --gpus 2` with NO external launcher: the parent (which touches no GPU API) spawns two fresh ranks
+    under torch.distributed.run, relays rank 0's single JSON line and exits 0.  gloo backend: both ranks share the one
+    card of this box, a rehearsal of the N > 1 code path (sharding by global chain id, barrier, max-over-ranks timing,
+    pool all-gather), not a scaling number."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--chains", "2048",
+                        "--nsteps", "200", "--steps", "2", "--warmup", "1", "--iters-per-step", "5", "--no-cpu-baseline"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, cwd=str(tmp_path), timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["config"]["chains_per_gpu"] == 2048
+    assert out["value"] > 0 and out["roofline"]["bound"] == "valu_fp64" and "pool_allgather_ms" in out
+
+
+def _rsf_problem(pkg, meta):
+    problem = pkg.RSF(**meta["rsf_kwargs"])
+    problem.model = pkg.RateStateModel(number_time_steps=meta["number_time_steps"])
+    problem.model.integrator = "dop853"      # the reference's own scheme: its numbers, not a convergence argument
+    problem.make_animations, problem.verbose = False, False
+    return problem
+
+
+def test_generate_time_series_equals_the_reference_vector(pkg, golden):
+    """A13 on the GPU: RSF.generate_time_series() under np.random.seed gives the reference's concatenated (num_dc*N,)
+    vector (tests/golden/rsf_driver.npz, written by the reference's RSF.generate_time_series, RSF.py:355-371)."""
+    g, meta = golden.npz("rsf_driver"), golden.json("rsf_driver")
+    problem = _rsf_problem(pkg, meta)
+    np.random.seed(meta["seed_data"])
+    data = problem.generate_time_series()
+    assert data.shape == g["data"].shape == (3 * 500,)
+    np.testing.assert_allclose(data, g["data"], rtol=1e-9, atol=1e-9 * np.abs(g["data"]).max())
+
+
+def test_inference_slices_and_chains_equal_the_reference(pkg, golden, tmp_path, monkeypatch):
+    """A14 on the GPU: RSF.inference() — JSON round trip, data[i*N:(i+1)*N] per Dc, one MCMC per Dc in dc_list order
+    from one RNG stream — gives the chains the reference's MCMC gives on those slices (RSF.py:874-894, 1040-1046)."""
+    g, meta = golden.npz("rsf_driver"), golden.json("rsf_driver")
+    monkeypatch.chdir(tmp_path)
+    problem = _rsf_problem(pkg, meta)
+    problem.data, problem.format = g["data"], "json"
+    np.random.seed(meta["seed_chains"])
+    with redirect_stdout(io.StringIO()):
+        seconds = problem.inference(meta["nsamples"])
+    assert seconds > 0
+    for i, dc in enumerate(g["dc_list"]):
+        np.testing.assert_allclose(problem.posteriors[float(dc)], g[f"qparams_{i}"], rtol=1e-9, err_msg=f"dc {dc}")

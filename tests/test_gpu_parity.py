@@ -412,14 +412,14 @@ def test_dop853_mode_matches_oracle_and_reference(gpu_engine, cpu_engine, oracle
         np.testing.assert_allclose(V[0, 0, 0], c["vstart"], rtol=1e-5, err_msg=name)
 
 
-@pytest.mark.parametrize("tag", ["list", "dict", "tightbox"])
+@pytest.mark.parametrize("tag", ["list", "dict", "dict3", "tightbox"])
 def test_dop853_mode_replays_the_reference_chain(gpu_engine, golden, oracle_mod, tag):
     """Same variates + same integrator: the GPU kernel walks the reference's chain, every iteration."""
     g, meta = golden.npz("replay_" + tag), golden.json("replay_" + tag)
     is_list = isinstance(meta["prior"], list)
     lo, hi = (meta["prior"][1], meta["prior"][2]) if is_list else (meta["prior"]["1"], meta["prior"]["2"])
     gpu_engine.set_model(_dp(oracle_mod, meta["nsteps"]), 1)
-    gpu_engine.mcmc_init([[meta["qstart"]]], g["data"], [lo], [hi], prior_len=3 if is_list else 2,
+    gpu_engine.mcmc_init([[meta["qstart"]]], g["data"], [lo], [hi], prior_len=len(meta["prior"]),
                          adapt_mode="none" if is_list else "reference_dict", adapt_interval=meta["adapt_interval"])
     _, ssq, std2, V = gpu_engine.get_state()
     np.testing.assert_allclose([ssq[0], std2[0]], [meta["ssq0"], meta["std2_0"]], rtol=1e-9)
@@ -706,12 +706,12 @@ def test_float32_solve_tolerance(pkg, oracle_mod):
 def test_replay_of_reference_variates(gpu_engine, golden, oracle_mod):
     """The reference's own recorded chain (tests/golden/replay_*.npz): feeding the GPU kernel the variates the
     reference consumed reproduces its accept decisions and samples up to the RK4-vs-dop853 difference."""
-    for tag, S in (("list", 8), ("dict", 8), ("tightbox", 8)):
+    for tag, S in (("list", 8), ("dict", 8), ("dict3", 8), ("tightbox", 8)):
         g, meta = golden.npz("replay_" + tag), golden.json("replay_" + tag)
         m = _models(oracle_mod, meta["nsteps"], S)
         gpu_engine.set_model(m, S)
         lo, hi = (meta["prior"][1], meta["prior"][2]) if isinstance(meta["prior"], list) else (meta["prior"]["1"], meta["prior"]["2"])
-        gpu_engine.mcmc_init([[meta["qstart"]]], g["data"], [lo], [hi], prior_len=3 if isinstance(meta["prior"], list) else 2,
+        gpu_engine.mcmc_init([[meta["qstart"]]], g["data"], [lo], [hi], prior_len=len(meta["prior"]),
                              adapt_mode="reference_dict" if meta["prior_is_dict"] else "none", adapt_interval=meta["adapt_interval"])
         q, ssq, std2, V = gpu_engine.get_state()
         np.testing.assert_allclose(std2[0], meta["std2_0"], rtol=1e-6)

@@ -43,7 +43,7 @@ def test_rate_state_model_surface(model, golden):
     np.testing.assert_array_equal(batch[1], model.evaluate()[1])
 
 
-@pytest.mark.parametrize("tag", ["list", "dict"])
+@pytest.mark.parametrize("tag", ["list", "dict", "dict3"])
 def test_mcmc_sample_reproduces_the_seeded_reference_chain(pkg, model, golden, tag):
     """np.random.seed selects the same chain as in the reference: same draw order from the global RNG
     (MCMC.py:497/331/160 + the unused randn(N) of every forward solve)."""
@@ -146,11 +146,12 @@ def test_rsf_driver_and_main_entry(pkg, oracle_lib, tmp_path, monkeypatch):
 
 def test_sample_batched_host_logic(pkg, model, golden, monkeypatch):
     """sample_batched slices the post-burn block correctly across several launches (oracle engine injected)."""
-    import bayesian_markov_chain_monte_carlo_amd.engine as eng_mod
+    import sys
 
+    mcmc_mod = sys.modules[pkg.MCMC.__module__]  # the module, not the class the package re-exports under the same name
     g = golden.npz("ssq")
     lib = model._engine.lib
-    monkeypatch.setattr(eng_mod, "Engine", lambda mem="host", device=-1, **k: pkg.Engine(lib=lib))
+    monkeypatch.setattr(mcmc_mod, "Engine", lambda mem="host", device=-1, **k: pkg.Engine(lib=lib))
     mc = pkg.MCMC(model, g["data"], 1000.0, ["Uniform", 0.0, 1e4], 1000.0, nsamples=20, lstm_model=None)
     one = mc.sample_batched(8, seed=4, mem="host")
     many = mc.sample_batched(8, seed=4, mem="host", iters_per_launch=7)
@@ -164,3 +165,122 @@ def test_sample_batched_host_logic(pkg, model, golden, monkeypatch):
     np.testing.assert_array_equal(thinned.std2, one.std2[::3])
     with pytest.raises(ValueError):
         mc.sample_batched(8, seed=4, mem="host", thin=0)
+
+
+def test_flat_module_imports_like_the_reference(tmp_path):
+    """The reference imports its modules flat (main.py:44-46, RSF.py:1-4, MCMC.py:1).  With the package directory first on
+    sys.path the very same statements must work (fresh interpreter: nothing of the package pre-imported), and the objects
+    must be the drop-in classes bound to the HIP library (which refuses to run here: no GPU, no CPU fallback)."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = """
+import sys
+sys.path.insert(0, sys.argv[1])
+from imports import *
+from RSF import RSF
+from RateStateModel import RateStateModel
+from MCMC import MCMC
+from json_save_load import save_object, load_object
+from RSF import measure_execution_time
+import main
+assert main.QPRIORS == ["Uniform", 0.0, 10000.0] and main.NSAMPLES == 500 and callable(main.setup_problem)
+assert "bayesian_markov_chain_monte_carlo_amd" not in sys.modules            # no package detour
+problem = RSF(number_slip_values=5, lowest_slip_value=100., largest_slip_value=5000., qstart=1000., qpriors=main.QPRIORS)
+problem.model = RateStateModel(number_time_steps=500)
+assert problem.dc_list.tolist() == [100.0, 1325.0, 2550.0, 3775.0, 5000.0] and problem.model.delta_t == 0.1
+mc = MCMC(problem.model, np.zeros(500), 100.0, main.QPRIORS, 1000.0, nsamples=10, lstm_model=None)
+assert mc.nburn == 5 and mc.qstart_limits.tolist() == [[0.0, 10000.0]]
+import _abi
+print("LIB", _abi.LIB_PATH)
+try:
+    problem.model.Dc = 100.0
+    problem.model.evaluate()
+except _abi.RsfError as e:
+    print("REFUSED", e)
+"""
+    r = subprocess.run([sys.executable, "-c", script, os.path.join(root, "bayesian-markov-chain-monte-carlo_amd")],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=str(tmp_path),
+                       env=dict(os.environ, MPLBACKEND="Agg"))
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert "csrc/librsf_hip.so" in r.stdout
+    import bayesian_markov_chain_monte_carlo_amd as pkg
+    if pkg._abi.load().rsf_device_count() == 0:
+        assert "REFUSED" in r.stdout and "no CPU fallback" in r.stdout
+
+
+def test_bench_self_launch_reports_child_failure(tmp_path):
+    """`python bench.py --gpus 2` starts its own ranks (no external launcher).  Without a GPU the ranks fail — the parent must
+    then exit non-zero and print no result line (with GPUs the same path is covered by tests/test_gpu_dropin.py)."""
+    import subprocess
+    import sys
+
+    import bayesian_markov_chain_monte_carlo_amd as pkg
+    if pkg._abi.load().rsf_device_count() > 0:
+        pytest.skip("GPU present: the successful self-launch is tested in test_gpu_dropin.py")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--chains", "256",
+                        "--nsteps", "100", "--steps", "1", "--warmup", "0", "--iters-per-step", "2", "--no-cpu-baseline"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, cwd=str(tmp_path), timeout=300)
+    assert r.returncode != 0
+    assert not [l for l in r.stdout.splitlines() if l.startswith('{"metric"')]
+    assert "child ranks exited with status" in r.stderr
+
+
+def _rsf_problem(pkg, meta, engine=None):
+    problem = pkg.RSF(**meta["rsf_kwargs"])
+    problem.model = pkg.RateStateModel(number_time_steps=meta["number_time_steps"])
+    problem.model.integrator = "dop853"      # the reference's own scheme: its numbers, not a convergence argument
+    if engine is not None:
+        problem.model._engine = engine       # test-only injection of the checker
+    problem.make_animations, problem.verbose = False, False
+    return problem
+
+
+def test_generate_time_series_equals_the_reference_vector(pkg, oracle_lib, golden):
+    """A13: RSF.generate_time_series() under np.random.seed gives the reference's concatenated (num_dc*N,) vector
+    (tests/golden/rsf_driver.npz, written by the reference's RSF.generate_time_series, RSF.py:355-371)."""
+    g, meta = golden.npz("rsf_driver"), golden.json("rsf_driver")
+    with pkg.Engine(lib=oracle_lib) as e:
+        problem = _rsf_problem(pkg, meta, e)
+        np.testing.assert_array_equal(problem.dc_list, g["dc_list"])
+        np.random.seed(meta["seed_data"])
+        data = problem.generate_time_series()
+    assert data.shape == g["data"].shape == (3 * 500,)
+    np.testing.assert_allclose(data, g["data"], rtol=1e-9, atol=1e-9 * np.abs(g["data"]).max())
+
+
+def test_inference_slices_and_chains_equal_the_reference(pkg, oracle_lib, golden, tmp_path, monkeypatch):
+    """A14: RSF.inference() — JSON round trip, data[i*N:(i+1)*N] per Dc, one MCMC per Dc in dc_list order from one RNG
+    stream — gives the chains the reference's MCMC gives on those slices (RSF.py:874-894, 1040-1046)."""
+    g, meta = golden.npz("rsf_driver"), golden.json("rsf_driver")
+    monkeypatch.chdir(tmp_path)
+    with pkg.Engine(lib=oracle_lib) as e:
+        problem = _rsf_problem(pkg, meta, e)
+        problem.data, problem.format = g["data"], "json"
+        np.random.seed(meta["seed_chains"])
+        with redirect_stdout(io.StringIO()):
+            problem.inference(meta["nsamples"])
+    for i, dc in enumerate(g["dc_list"]):
+        np.testing.assert_allclose(problem.posteriors[float(dc)], g[f"qparams_{i}"], rtol=1e-9, err_msg=f"dc {dc}")
+    # a wrong slice cannot pass: the three chains differ from one another by far more than the tolerance
+    assert not np.allclose(g["qparams_0"], g["qparams_1"], rtol=1e-3)
+
+
+def test_reference_written_json_files(pkg, golden, tmp_path):
+    """Files written by the reference's own json_save_load.save_object (tests/golden/ref_written_*.json) load here, and
+    this module's save_object writes the same bytes."""
+    from bayesian_markov_chain_monte_carlo_amd import json_save_load as J
+
+    for name in ("ref_written_array", "ref_written_dict"):
+        src = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name + ".json")
+        obj = J.load_object(src)
+        J.save_object(obj, tmp_path / "again.json")
+        assert open(src, "rb").read() == open(tmp_path / "again.json", "rb").read(), name
+    arr = J.load_object(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_written_array.json"))
+    assert isinstance(arr, np.ndarray) and arr.shape == (12,) and arr.dtype == np.float64
+    np.testing.assert_array_equal(arr, np.random.default_rng(3).standard_normal(12) * 1e-3)
+    d = J.load_object(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_written_dict.json"))
+    assert d["grid"].shape == (2, 3) and d["ints"].tolist() == [0, 1, 2, 3] and d["meta"] == {"dc": 1000.0, "n": 12, "tags": ["a", "b"]}

@@ -165,7 +165,7 @@ def test_initial_covariance_against_reference(cpu_engine, oracle_mod, golden):
         np.testing.assert_allclose(V[0, 0, 0], c["vstart"], rtol=5e-3, err_msg=name)
 
 
-@pytest.mark.parametrize("tag", ["list", "dict", "tightbox"])
+@pytest.mark.parametrize("tag", ["list", "dict", "dict3", "tightbox"])
 def test_sampler_logic_replays_reference_exactly(oracle_mod, golden, tag):
     """Feeding the recorded variates AND the recorded SSq values through the restated sampler logic must
     give the reference's chain bit-for-bit (accept rule, sigma^2 update, adaptation quirks)."""
@@ -186,18 +186,18 @@ def test_sampler_logic_replays_reference_exactly(oracle_mod, golden, tag):
     np.testing.assert_allclose(s.std2[nb:], g["std2_kept"], rtol=1e-13)
     if tag == "tightbox":
         assert (g["inb"] == 0).sum() > 5  # the fixture really exercises out-of-bounds proposals
-    if tag == "dict":
+    if tag in ("dict", "dict3"):
         assert len(set(np.round(g["vold"], 6))) > 3  # and the dict prior really adapts
 
 
-@pytest.mark.parametrize("tag", ["list", "dict", "tightbox"])
+@pytest.mark.parametrize("tag", ["list", "dict", "dict3", "tightbox"])
 def test_c_oracle_replays_reference_chain(cpu_engine, oracle_mod, golden, tag):
     """C restatement with its own RK4 (S = 8) forward model, driven by the reference's variates."""
     g, meta = golden.npz("replay_" + tag), golden.json("replay_" + tag)
     is_list = isinstance(meta["prior"], list)
     lo, hi = (meta["prior"][1], meta["prior"][2]) if is_list else (meta["prior"]["1"], meta["prior"]["2"])
     cpu_engine.set_model(oracle_mod.ModelSpec(meta["nsteps"], substeps=8), 8)
-    cpu_engine.mcmc_init([[meta["qstart"]]], g["data"], [lo], [hi], prior_len=3 if is_list else 2,
+    cpu_engine.mcmc_init([[meta["qstart"]]], g["data"], [lo], [hi], prior_len=len(meta["prior"]),
                          adapt_mode="none" if is_list else "reference_dict", adapt_interval=meta["adapt_interval"])
     _, ssq, std2, _ = cpu_engine.get_state()
     np.testing.assert_allclose([ssq[0], std2[0]], [meta["ssq0"], meta["std2_0"]], rtol=1e-6)
@@ -306,14 +306,14 @@ def test_dop853_ssq_and_initial_covariance_match_reference(cpu_engine, oracle_mo
         np.testing.assert_allclose(V[0, 0, 0], c["vstart"], rtol=1e-6, err_msg=name)  # 1e-6 forward difference of ~1e-12 noise
 
 
-@pytest.mark.parametrize("tag", ["list", "dict", "tightbox"])
+@pytest.mark.parametrize("tag", ["list", "dict", "dict3", "tightbox"])
 def test_dop853_chain_equals_reference_chain(cpu_engine, oracle_mod, golden, tag):
     """Same variates + same integrator = the reference's chain, every iteration (no recorded SSq injected)."""
     g, meta = golden.npz("replay_" + tag), golden.json("replay_" + tag)
     is_list = isinstance(meta["prior"], list)
     lo, hi = (meta["prior"][1], meta["prior"][2]) if is_list else (meta["prior"]["1"], meta["prior"]["2"])
     cpu_engine.set_model(_dp_model(oracle_mod, meta["nsteps"]), 1)
-    cpu_engine.mcmc_init([[meta["qstart"]]], g["data"], [lo], [hi], prior_len=3 if is_list else 2,
+    cpu_engine.mcmc_init([[meta["qstart"]]], g["data"], [lo], [hi], prior_len=len(meta["prior"]),
                          adapt_mode="none" if is_list else "reference_dict", adapt_interval=meta["adapt_interval"])
     _, ssq, std2, V = cpu_engine.get_state()
     np.testing.assert_allclose([ssq[0], std2[0]], [meta["ssq0"], meta["std2_0"]], rtol=1e-11)

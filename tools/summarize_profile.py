@@ -59,7 +59,7 @@ def main():
         summary["note_units"] = "SQ_* cycle counters are in quad-cycles summed over SEs/XCDs (MI355X_MICROARCH.md)"
     # the bench line printed under the kernel-trace pass: kept beside the summaries; its proposals per launch say
     # which launch shape the per-launch counters belong to
-    ips = None
+    ips = bench_roof = None
     log = os.path.join(src, "trace.log")
     if os.path.exists(log):
         lines = [l for l in open(log) if l.startswith('{"metric"')]
@@ -67,8 +67,19 @@ def main():
             bench = json.loads(lines[-1])
             ips = bench["config"].get("proposals_per_chain_per_step")
             summary["bench_kernel_ms_hip_events"] = bench["roofline"].get("kernel_ms")
+            bench_roof = bench["roofline"] if "rk4_steps_per_s" in bench["roofline"] else bench.get("roofline_valu")
+            if bench_roof is not None:
+                bench_roof = dict(bench_roof, kernel_ms=bench["roofline"].get("kernel_ms"))
             json.dump(bench, open(os.path.join(dst, f"{tag}_{build}_bench.json"), "w"))
     summary["proposals_per_chain_per_launch"] = ips
+    if bench_roof and "SQ_INSTS_VALU" in pmc and "GRBM_GUI_ACTIVE" in pmc:
+        # SQ_INSTS_VALU counts wave-instructions; each occupies a SIMD's fp64 pipe for 4 cycles; 1024 SIMDs; GRBM_GUI_ACTIVE is
+        # summed over the 8 XCDs.  RK4 steps per launch come from the bench line of the kernel-trace pass (same launch shape).
+        wave_steps = bench_roof["rk4_steps_per_s"] * bench_roof["kernel_ms"] * 1e-3 / 64.0
+        summary["valu_insts_per_rk4_step"] = pmc["SQ_INSTS_VALU"] / wave_steps
+        summary["salu_insts_per_rk4_step"] = pmc.get("SQ_INSTS_SALU", 0.0) / wave_steps
+        summary["pipe_busy"] = 4.0 * pmc["SQ_INSTS_VALU"] / 1024.0 / (pmc["GRBM_GUI_ACTIVE"] / 8.0)
+        summary["clock_ghz"] = pmc["GRBM_GUI_ACTIVE"] / 8.0 / (summary["avg_ms"] * 1e-3) / 1e9
     json.dump(summary, open(os.path.join(dst, f"{tag}_{build}_pmc.json"), "w"), indent=1)
     tfile = os.path.join(os.path.dirname(dst.rstrip("/")), "pmc_traffic.json")
     traffic = json.load(open(tfile)) if os.path.exists(tfile) else {}
@@ -76,6 +87,8 @@ def main():
         traffic[tag] = summary["hbm_bytes_per_launch"]["total_corrected"]
         traffic[tag + "_source"] = f"{dst}/{tag}_{build}_pmc.json"
         traffic[tag + "_iters_per_step"] = ips
+        traffic[tag + "_valu_per_rk4_step"] = summary.get("valu_insts_per_rk4_step")
+        traffic[tag + "_pipe_busy"] = summary.get("pipe_busy")
         json.dump(traffic, open(tfile, "w"), indent=1)
     print(json.dumps(summary, indent=1))
 
