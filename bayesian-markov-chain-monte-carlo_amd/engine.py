@@ -130,6 +130,7 @@ class Engine:
         n = ctypes.c_int32()
         _abi.check(self.lib, self.lib.rsf_model_nout(self._ctx, ctypes.byref(n)))
         self.nout = n.value
+        self.model_args = (model, substeps)
         self.n_chains = self.n_params = None  # a new model invalidates the chains (rsf_abi.h: rsf_set_model)
         return self.nout
 
