@@ -43,9 +43,13 @@ WORKLOADS = {
     # BASELINE.json configs[1] / configs[2]
     "cfg1": dict(chains=65536, nsteps=500, desc="configs[1]: 65536 chains x nsteps 500, fp64"),
     "cfg2": dict(chains=262144, nsteps=2000, desc="configs[2]: 262144 chains x nsteps 2000, fp64"),
+    # one GPU's share of configs[4]: joint (Dc, a, b), 1 048 576 / 8 chains, nsteps 4000 (profiling / tolerance-sweep shape)
+    "cfg5": dict(chains=131072, nsteps=4000, n_params=3, desc="configs[4] per-GPU shard: 131072 chains x nsteps 4000, joint (Dc, a, b)"),
 }
+START = [1000.0, 0.011, 0.014]                 # chain start and prior box of the 3-parameter problem
+BOX_LO, BOX_HI = [0.0, 0.005, 0.005], [1.0e4, 0.02, 0.03]
+PROPOSAL_STD = [20.0, 1.0e-4, 1.0e-4]          # explicit proposal covariance for d = 3: (X^T X)^-1 is near-singular there
 FLOPS_PER_RK4_STEP = 152.0       # 4 RHS x 27 + RK4 combine 39 + observation/SSq 5
-BYTES_PER_PROPOSAL = 16.0        # 8 B sample + 8 B sigma^2 written per chain-proposal (d = 1)
 PEAK_HBM_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 PEAK_FP64_VALU_TFLOPS = 78.6     # 256 CU x 4 SIMD x 16 fp64 FMA lanes x 2 flop x 2.4 GHz
 
@@ -204,16 +208,18 @@ def self_launch(n_gpus):
     sys.exit(0)
 
 
-def time_sampler(pkg, model, data, C, ips, steps, warmup, rank, barrier):
+def time_sampler(pkg, model, data, C, ips, steps, warmup, rank, barrier, d=1):
     """W untimed + K timed launches of the fused sampler (ips proposals per chain each) on `C` chains of this rank.
     → (wall seconds of the K launches, mean kernel ms from HIP events on the launch stream, stats, engine, traces)."""
     import torch
 
     eng = pkg.Engine(mem="device")
     nout = eng.set_model(model, 1)
-    q0 = torch.full((C, 1), 1000.0, dtype=torch.float64, device="cuda")
-    eng.mcmc_init(q0, data, [0.0], [1.0e4], seed=2025, chain_offset=rank * C, prior_len=3, adapt_mode="none")
-    traces = (torch.empty((ips, C, 1), dtype=torch.float64, device="cuda"),
+    q0 = torch.tensor(START[:d], dtype=torch.float64, device="cuda").repeat(C, 1)
+    eng.mcmc_init(q0, data, BOX_LO[:d], BOX_HI[:d], seed=2025, chain_offset=rank * C, prior_len=3 if d == 1 else 0, adapt_mode="none")
+    if d > 1:
+        eng.set_state(V=torch.diag(torch.tensor(PROPOSAL_STD[:d], dtype=torch.float64, device="cuda") ** 2).repeat(C, 1, 1))
+    traces = (torch.empty((ips, C, d), dtype=torch.float64, device="cuda"),
               torch.empty((ips, C), dtype=torch.float64, device="cuda"), None)
     for _ in range(warmup):
         eng.mcmc_run(ips, out=traces)
@@ -230,12 +236,13 @@ def time_sampler(pkg, model, data, C, ips, steps, warmup, rank, barrier):
     return wall, kernel_ms, eng.stats(), eng, traces, nout
 
 
-def roofline_views(workload, custom, C, ips, nout, stats, kernel_ms):
+def roofline_views(workload, custom, C, ips, nout, stats, kernel_ms, d=1, mode="RK4"):
     """The two roofline views of one launch of the sampler kernel."""
     evaluated = stats["evaluated"] / max(1, stats["iters_done"] * C)
     per_launch_props = C * ips
     rk4_steps_per_launch = per_launch_props * (nout - 1) * evaluated
-    hbm_gbs = BYTES_PER_PROPOSAL * per_launch_props / (kernel_ms * 1e-3) / 1e9
+    bytes_per_proposal = 8.0 * d + 8.0   # sample (d doubles) + sigma^2 written per chain-proposal
+    hbm_gbs = bytes_per_proposal * per_launch_props / (kernel_ms * 1e-3) / 1e9
     tflops = FLOPS_PER_RK4_STEP * rk4_steps_per_launch / (kernel_ms * 1e-3) / 1e12
     pmc = {}
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
@@ -248,15 +255,15 @@ def roofline_views(workload, custom, C, ips, nout, stats, kernel_ms):
                    "pmc_source": f"rocprofv3 PMC passes of this launch shape, {t.get(workload + '_source')} — stored, not measured in this run"}
     valu = {"bound": "valu_fp64", "achieved": tflops, "peak": PEAK_FP64_VALU_TFLOPS, "unit": "TFLOP/s",
             "frac": tflops / PEAK_FP64_VALU_TFLOPS, "traffic": pmc.get("traffic"),
-            "kernel": "mcmc_kernel<1,damp,philox,RK4>", "kernel_ms": kernel_ms,
+            "kernel": f"mcmc_kernel<{d},damp,philox,{mode}>", "kernel_ms": kernel_ms,
             "flops_per_rk4_step": FLOPS_PER_RK4_STEP, "rk4_steps_per_s": rk4_steps_per_launch / (kernel_ms * 1e-3),
             "valu_insts_per_rk4_step": pmc.get("valu_insts_per_rk4_step"), "pipe_busy": pmc.get("pipe_busy"),
             "pmc_source": pmc.get("pmc_source"),
             "note": "fp64 VALU issue binds (no MFMA: elementwise ODE recurrence); peak = 256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz; "
                     "pipe_busy = 4 cycles x SQ_INSTS_VALU / SIMDs / GRBM_GUI_ACTIVE is the utilisation figure, frac the nominal-flop one"}
     hbm = {"bound": "hbm", "achieved": hbm_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": hbm_gbs / PEAK_HBM_GBS,
-           "traffic": pmc.get("traffic"), "algorithmic_bytes_per_launch": BYTES_PER_PROPOSAL * per_launch_props,
-           "note": "HBM view the metric names: 16 B written per chain-proposal; arithmetic intensity ~4750 flop/B, not the binding bound"}
+           "traffic": pmc.get("traffic"), "algorithmic_bytes_per_launch": bytes_per_proposal * per_launch_props,
+           "note": f"HBM view the metric names: {bytes_per_proposal:.0f} B written per chain-proposal; arithmetic intensity ~4750 flop/B, not the binding bound"}
     return valu, hbm, evaluated
 
 
@@ -271,6 +278,9 @@ def main():
     ap.add_argument("--iters-per-step", type=int, default=100, help="proposals per chain per launch (SURVEY §8d: 100)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-also", action="store_true", help="skip the secondary configs[1] measurement")
+    ap.add_argument("--integrator", default="rk4", choices=["rk4", "dop853"],
+                    help="dop853 = the reference's own adaptive scheme (side measurement / profiling; the metric is quoted on rk4)")
+    ap.add_argument("--precision", default="float64", choices=["float64", "float32"], help="float32 = config-5 tolerance-sweep solve")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend for N > 1 (nccl = RCCL; gloo only to rehearse the N > 1 path on one GPU)")
     args = ap.parse_args()
@@ -301,6 +311,9 @@ def main():
 
     wl = WORKLOADS[args.workload]
     custom = bool(args.chains or args.nsteps)
+    d = wl.get("n_params", 1)
+    variant = ("_dop853" if args.integrator == "dop853" else "") + ("_f32" if args.precision == "float32" else "")
+    mode = "DOP853" if args.integrator == "dop853" else ("RK4/f32" if args.precision == "float32" else "RK4")
     C = args.chains or wl["chains"]          # per GPU: weak scaling
     nsteps = args.nsteps or wl["nsteps"]
     ips = args.iters_per_step
@@ -312,7 +325,9 @@ def main():
         torch.cuda.synchronize()
 
     model, data = synthetic_problem(nsteps)
-    wall, kernel_ms, stats, eng, traces, nout = time_sampler(pkg, model, data, C, ips, args.steps, args.warmup, rank, barrier)
+    model.integrator, model.precision = args.integrator, args.precision
+    wall, kernel_ms, stats, eng, traces, nout = time_sampler(pkg, model, data, C, ips, args.steps, args.warmup, rank, barrier, d)
+    model.integrator, model.precision = "rk4", "float64"
 
     if world > 1:
         t = torch.tensor([wall], dtype=torch.float64, device=coll_dev)
@@ -324,21 +339,26 @@ def main():
         pool = rdist.pool_to_chain_major(rdist.allgather_pool(traces[0].to(coll_dev)))
         torch.cuda.synchronize()
         allgather_ms = (time.perf_counter() - g0) * 1e3
-        assert pool.shape == (ips, world * C, 1)
+        assert pool.shape == (ips, world * C, d)
         abi_pool = abi_pool_allgather(eng, traces[0], pool, rdist) if args.backend == "nccl" else None
     else:
         allgather_ms = abi_pool = None
 
     if rank == 0:
         value = world * C * ips * args.steps * nsteps / wall
-        valu, hbm, evaluated = roofline_views(args.workload, custom, C, ips, nout, stats, kernel_ms)
+        valu, hbm, evaluated = roofline_views(args.workload + variant, custom, C, ips, nout, stats, kernel_ms, d, mode)
+        if mode != "RK4":
+            valu["note"] = ("side measurement, not the headline arithmetic: " + ("the reference's adaptive DOP853 scheme — the unit of "
+                            "rk4_steps_per_s is one OUTPUT INTERVAL (>= 1 step of 12 stages), flops are not counted, frac is nominal only"
+                            if mode == "DOP853" else "float32 ODE solve (hardware v_exp/v_log/v_rcp_f32); frac still normalised by the fp64 peak"))
         out = {
             "metric": "ode_steps_x_chains_per_sec", "value": value, "unit": "ODE-steps*chains/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": wl["desc"] if not custom else f"custom: {C} chains x nsteps {nsteps}, fp64",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64" if args.precision == "float64" else "f32 solve, f64 sampler",
+            "data": "synthetic",
+            "config": {"workload": (wl["desc"] if not custom else f"custom: {C} chains x nsteps {nsteps}, fp64") + (f" [{mode}]" if mode != "RK4" else ""),
                        "chains_per_gpu": C, "nsteps": nsteps, "rk4_substeps": 1, "proposals_per_chain_per_step": ips,
-                       "n_params": 1, "adapt_mode": "none", "parallelism": f"chains sharded over {world} GPU(s), no data-path collective",
+                       "n_params": d, "adapt_mode": "none", "integrator": args.integrator, "parallelism": f"chains sharded over {world} GPU(s), no data-path collective",
                        "evaluated_fraction": evaluated,
                        "acceptance": stats["accepted"] / max(1, stats["iters_done"] * C)},
             "roofline": valu, "roofline_hbm": hbm,
@@ -351,7 +371,7 @@ def main():
         eng.close()
         del traces
         torch.cuda.empty_cache()
-        if not args.no_also and not custom:
+        if not args.no_also and not custom and d == 1 and mode == "RK4":
             # the other single-GPU BASELINE configuration, same process, same method (secondary figure)
             other = "cfg1" if args.workload == "cfg2" else "cfg2"
             wo = WORKLOADS[other]
@@ -366,7 +386,7 @@ def main():
             eng_o.close()
             del tr_o
             torch.cuda.empty_cache()
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and d == 1 and mode == "RK4":
             out["reference_scheme"] = reference_scheme_rate(model, data, C, nsteps)
             out["cpu_baseline"] = cpu_baseline(model, data)
     if rank == 0:

@@ -231,5 +231,11 @@ def test_inference_slices_and_chains_equal_the_reference(pkg, golden, tmp_path, 
     with redirect_stdout(io.StringIO()):
         seconds = problem.inference(meta["nsamples"])
     assert seconds > 0
+    # every kept sample of every chain.  Tolerance 2e-8, not 1e-9: the proposal std sqrt(Vstart) comes from a forward difference
+    # with relative step 1e-6 (MCMC.py:251) that amplifies the ~1e-12 GPU-vs-libm rounding of the trajectories to ~1e-7 in
+    # Vstart (DESIGN §5 "known limit"), and q = q_cur + sqrt(Vstart) z carries half of that times sqrt(V) z / q (measured
+    # 1.6e-9 at Dc = 500).  The three chains differ from one another at the 1e-1 level, so a wrong slice cannot pass; the
+    # CPU twin of this test (test_host_logic.py, oracle engine) holds 1e-9.
     for i, dc in enumerate(g["dc_list"]):
-        np.testing.assert_allclose(problem.posteriors[float(dc)], g[f"qparams_{i}"], rtol=1e-9, err_msg=f"dc {dc}")
+        np.testing.assert_allclose(problem.posteriors[float(dc)], g[f"qparams_{i}"], rtol=2e-8, err_msg=f"dc {dc}")
+    assert not np.allclose(g["qparams_0"], g["qparams_1"], rtol=1e-2) and not np.allclose(g["qparams_1"], g["qparams_2"], rtol=1e-2)
