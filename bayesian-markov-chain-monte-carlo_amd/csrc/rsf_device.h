@@ -54,11 +54,14 @@ struct Lane {
   double kprime;  // k'
   double kia;     // k'/a          : d(mu)/a = kia * d(ms)
   double khh, kh, kh6;  // kia*(h/2), kia*h, kia*(h/6): d(mu)/a of a stage / step straight from the ms derivative
-  double k1k;     // k1/k'         : radiation damping in ms units
-  double via;     // V_ref/a
-  double vk, vb;  // (V_ref/a) k', (V_ref/a) b/Dc : dV/dt = w (vk d0 - vb d1/x)
-  double c3;      // vb - vk V_ref : coefficient of w in that bracket once d0 and d1/x are written out (rhs_fast)
-  double bdc;     // b/Dc          : b/theta = bdc / x
+  // dV/dt = (v/a)(dmu/dt - b/theta dtheta/dt) = vk w g with g = d0 - beta d1/x (d0 = V_l - v = d(ms)/dt): the integrator works on
+  // g, i.e. on dV/dt in units of vk per unit w — vk multiplies only the finished sample (cv), not every stage
+  double vk;      // (V_ref/a) k'
+  double beta;    // (b/theta dtheta/dt)/(k' d(ms)/dt) coefficient: (V_ref b/Dc)/k' = 10 b V_ref (independent of Dc)
+  double c3;      // beta - V_ref  : coefficient of w in g once d0 and d1/x are written out (rhs_fast)
+  double kvk;     // (k1/k') vk = k1 V_ref/a : radiation damping, d0 -= kvk w g
+  double cv;      // cacc vk       : acceleration sample = cv * (g-weighted RK4 sum of the step)
+  double h6v;     // (h/6) vk      : velocity increment of a step = h6v * that sum
   double boa;     // b/a
   double tc;      // -mu_ref/a
   double hhd, hd, h6d;  // (h/2)/Dc, h/Dc, (h/6)/Dc : theta increments in x units
@@ -85,13 +88,14 @@ __device__ __forceinline__ Lane make_lane(double dc, double a, double b, const C
   L.khh = L.kia * K.hh;
   L.kh = L.kia * K.h;
   L.kh6 = L.kia * K.h6;
-  L.k1k = (K.k1 * dc) * (1.0 / (1e-2 * 10));  // k1/k'
-  L.via = K.V_ref * inv_a;
+  const double via = K.V_ref * inv_a;
   L.vdc = K.V_ref * L.inv_dc;
-  L.bdc = b * L.vdc;               // b/theta = (b V_ref/Dc) / x
-  L.vk = L.via * L.kprime;
-  L.vb = L.via * L.bdc;
-  L.c3 = __builtin_fma(-L.vk, K.V_ref, L.vb);
+  L.vk = via * L.kprime;
+  L.beta = (b * K.V_ref) * (1.0 / (1e-2 * 10));
+  L.c3 = L.beta - K.V_ref;
+  L.kvk = K.k1 * via;
+  L.cv = K.cacc * L.vk;
+  L.h6v = K.h6 * L.vk;
   L.boa = b * inv_a;
   L.tc = -K.mu_ref * inv_a;
   L.hhd = K.hh * L.vdc;
@@ -114,38 +118,39 @@ struct State {
   double w, rx;
 };
 
-// the RHS once w and 1/x are known.  d0 = d(ms)/dt, d1 = d(theta)/dt (so dx = d1/Dc), d2 = dV/dt.
+// the RHS once w and 1/x are known.  d0 = d(ms)/dt, d1 = d(theta)/dt (so dx = d1/Dc), d2 = (dV/dt)/vk.
 template <bool DAMP>
 __device__ __forceinline__ void rhs_tail(double w, double rx, double x, double vl, const Lane &L,
                                          const Consts &K, double &d0, double &d1, double &d2) {
   d1 = __builtin_fma(-w, x, 1.0);                    // ageing law: 1 - v*theta/Dc
   d0 = __builtin_fma(-K.V_ref, w, vl);               // spring loading / k':  V_l - v
-  const double bt = (L.vb * d1) * rx;                // (V_ref/a) b/theta * dtheta/dt
-  double in = __builtin_fma(L.vk, d0, -bt);          // dV/dt = w * in:  v/a (dmu/dt - b/theta dtheta/dt), RateStateModel.py:346
+  const double bt = (L.beta * d1) * rx;              // b/theta * dtheta/dt, in units of k'
+  double g = d0 - bt;                                // dV/dt = vk w g:  v/a (dmu/dt - b/theta dtheta/dt), RateStateModel.py:346
   if (DAMP) {                                        // one fixed-point pass, RateStateModel.py:349-353: d0 -= k1/k' * dV/dt,
-    d0 = __builtin_fma(-(L.k1k * w), in, d0);        //   then dV/dt again; the first dV/dt = w * in is never formed, which
-    in = __builtin_fma(L.vk, d0, -bt);               //   keeps the chain d1 -> bt -> in -> d0 one instruction shorter
+    d0 = __builtin_fma(-(L.kvk * w), g, d0);         //   then dV/dt again
+    g = d0 - bt;
   }
-  d2 = w * in;
+  d2 = w * g;
 }
 
 // The same RHS arranged for the hot loop, where w arrives last (it ends the dependency chain of the previous stage):
-// with d1/x = 1/x - w the bracket of dV/dt is LINEAR in w,
-//     in = vk (V_l - V_ref w) - vb (1/x - w) = (vk V_l - vb/x) + (vb - vk V_ref) w,
+// with d1/x = 1/x - w the bracket g of dV/dt = vk w g is LINEAR in w,
+//     g = (V_l - V_ref w) - beta (1/x - w) = (V_l - beta/x) + (beta - V_ref) w,
 // so everything but one fma is ready before w is, and the damped d0 follows two instructions after w instead of
-// five.  (vb/x and vb w nearly cancel, but against vk V_l their rounding is ~3e-17 of the result.)
+// five.  (beta/x and beta w nearly cancel, but against V_l their rounding is ~3e-17 of the result.)  Working on g rather
+// than on vk g makes the damping pass ONE product shared by both corrections: d0 -= (kvk w) g and g -= (kvk w) g.
+// The caller forms w g (the stage's dV/dt in units of vk) inside its weighted sum.
 template <bool DAMP>
 __device__ __forceinline__ void rhs_fast(double w, double x, double vl, double t1, const Lane &L, const Consts &K, double &d0,
-                                         double &d1, double &d2) {  // t1 = vk V_l - vb/x, formed by the caller (no w in it)
+                                         double &d1, double &g) {  // t1 = V_l - beta/x, formed by the caller (no w in it)
   d1 = __builtin_fma(-w, x, 1.0);
   d0 = __builtin_fma(-K.V_ref, w, vl);
-  double in = __builtin_fma(L.c3, w, t1);
-  if (DAMP) {  // d0 -= k1/k' * (w in); then in again with the damped d0: in - vk (k1/k' w) in
-    const double kw = L.k1k * w;
-    d0 = __builtin_fma(-kw, in, d0);
-    in = __builtin_fma(-(L.vk * kw), in, in);
+  g = __builtin_fma(L.c3, w, t1);
+  if (DAMP) {
+    const double kw = L.kvk * w;
+    d0 = __builtin_fma(-kw, g, d0);
+    g = __builtin_fma(-kw, g, g);
   }
-  d2 = w * in;
 }
 
 // (w, 1/x) by full evaluation
@@ -178,11 +183,11 @@ __device__ __forceinline__ void eval_full(double ms, double x, const Lane &L, co
 enum Tier : int { TIGHT = 0, NARROW = 1, WIDE = 2 };
 
 // t1 of a stage.  TIGHT stages never form 1/x at the stage point: with 1/x' = (1/x)(1 + q), q = rho^2 - rho (eval_incr
-// hands q back in place of 1/x'), vb/x' = vbr0 + vbr0 q where vbr0 = vb/x at the step's start.
+// hands q back in place of 1/x'), beta/x' = br0 + br0 q where br0 = beta/x at the step's start.
 template <int T>
-__device__ __forceinline__ double stage_t1(double vl, double rx_or_q, double vbr0, const Lane &L) {
-  if (T == TIGHT) return __builtin_fma(-vbr0, rx_or_q, __builtin_fma(L.vk, vl, -vbr0));
-  return __builtin_fma(-L.vb, rx_or_q, L.vk * vl);
+__device__ __forceinline__ double stage_t1(double vl, double rx_or_q, double br0, const Lane &L) {
+  if (T == TIGHT) return __builtin_fma(-br0, rx_or_q, vl - br0);
+  return __builtin_fma(-L.beta, rx_or_q, vl);
 }
 
 
@@ -301,8 +306,8 @@ __device__ __forceinline__ bool guard_ok(const Guard &g) {  // NaN passes throug
 #define RSF_RESYNC 128
 #endif
 
-// Both step functions return the weighted sum of the V derivatives, k1 + 2 k2 + 2 k3 + k4: the velocity increment of
-// the step is (h/6) times it.  V itself never feeds back into the RHS, so the hot loop does not carry it: with one
+// Both step functions return the weighted sum of the V derivatives, k1 + 2 k2 + 2 k3 + k4, IN UNITS OF vk (rhs_tail /
+// rhs_fast): the velocity increment of the step is (h/6) vk = L.h6v times it.  V itself never feeds back into the RHS, so the hot loop does not carry it: with one
 // step per output sample the acceleration (V_k - V_{k-1})/delta_t (RateStateModel.py:388) IS cacc * sum.
 template <bool DAMP>
 __device__ __forceinline__ double rk4_cold(State &s, double vl0, double vlm, double vl1, const Lane &L,
@@ -333,17 +338,21 @@ __device__ __forceinline__ double rk4_fast(State &s, double vl0, double vlm, dou
                                            const Consts &K, Guard &g) {
   double a0, a1, a2, b0, b1, b2, c0, c1, c2, e0, e1, e2, w, rx, xs;
   const double Rh = L.hhd * s.rx, Rf = Rh + Rh, R6 = L.h6d * s.rx;  // rho of a stage = its theta derivative times these
-  const double vbr0 = L.vb * s.rx;
-  rhs_fast<DAMP>(s.w, s.x, vl0, __builtin_fma(L.vk, vl0, -vbr0), L, K, a0, a1, a2);
+  const double br0 = L.beta * s.rx;
+  rhs_fast<DAMP>(s.w, s.x, vl0, vl0 - br0, L, K, a0, a1, a2);
+  double sv = s.w * a2;  // k1 + k4 of dV/dt (in units of vk), and k2 + k3 below: 5 instructions for the weighted sum
   xs = __builtin_fma(L.hhd, a1, s.x);
   eval_incr<T, true, true>(L.khh, a0, Rh, a1, xs, L, s.w, s.rx, w, rx, g);
-  rhs_fast<DAMP>(w, xs, vlm, stage_t1<T>(vlm, rx, vbr0, L), L, K, b0, b1, b2);
+  rhs_fast<DAMP>(w, xs, vlm, stage_t1<T>(vlm, rx, br0, L), L, K, b0, b1, b2);
+  double sm = w * b2;
   xs = __builtin_fma(L.hhd, b1, s.x);
   eval_incr<T, true, true>(L.khh, b0, Rh, b1, xs, L, s.w, s.rx, w, rx, g);
-  rhs_fast<DAMP>(w, xs, vlm, stage_t1<T>(vlm, rx, vbr0, L), L, K, c0, c1, c2);
+  rhs_fast<DAMP>(w, xs, vlm, stage_t1<T>(vlm, rx, br0, L), L, K, c0, c1, c2);
+  sm = __builtin_fma(w, c2, sm);
   xs = __builtin_fma(L.hd, c1, s.x);
   eval_incr<T, true>(L.kh, c0, Rf, c1, xs, L, s.w, s.rx, w, rx, g);
-  rhs_fast<DAMP>(w, xs, vl1, stage_t1<T>(vl1, rx, vbr0, L), L, K, e0, e1, e2);
+  rhs_fast<DAMP>(w, xs, vl1, stage_t1<T>(vl1, rx, br0, L), L, K, e0, e1, e2);
+  sv = __builtin_fma(w, e2, sv);
   const double t0 = a0 + 2.0 * b0 + 2.0 * c0 + e0;
   const double t1 = a1 + 2.0 * b1 + 2.0 * c1 + e1;
   const double x1 = __builtin_fma(L.h6d, t1, s.x);
@@ -352,7 +361,7 @@ __device__ __forceinline__ double rk4_fast(State &s, double vl0, double vlm, dou
   s.x = x1;
   s.w = w;
   s.rx = rx;
-  return a2 + 2.0 * b2 + 2.0 * c2 + e2;
+  return __builtin_fma(2.0, sm, sv);
 }
 
 // advance one step; `resync` (wave-uniform, from the step index) asks for a full re-evaluation of (w, 1/th) first
@@ -360,7 +369,7 @@ template <bool DAMP>
 __device__ __forceinline__ void rk4_step(State &s, bool resync, double vl0, double vlm, double vl1, const Lane &L,
                                          const Consts &K) {
 #ifdef RSF_NO_INCREMENTAL
-  s.V = __builtin_fma(K.h6, rk4_cold<DAMP>(s, vl0, vlm, vl1, L, K), s.V);
+  s.V = __builtin_fma(L.h6v, rk4_cold<DAMP>(s, vl0, vlm, vl1, L, K), s.V);
   (void)resync;
 #else
   if (resync) eval_full(s.ms, s.x, L, K, s.w, s.rx);
@@ -372,7 +381,7 @@ __device__ __forceinline__ void rk4_step(State &s, bool resync, double vl0, doub
     dv = rk4_cold<DAMP>(s, vl0, vlm, vl1, L, K);
     eval_full(s.ms, s.x, L, K, s.w, s.rx);
   }
-  s.V = __builtin_fma(K.h6, dv, save.V);
+  s.V = __builtin_fma(L.h6v, dv, save.V);
 #endif
 }
 
@@ -429,13 +438,13 @@ __device__ __forceinline__ void emit_at(double vnow, double vprev, int ko, doubl
   }
 }
 
-// the same sample straight from the step's derivative sum (one step per output sample): ak = cacc * dvs
+// the same sample straight from the step's derivative sum (one step per output sample): ak = cacc vk * dvs
 template <bool WANT_SSQ, bool WANT_ACC>
-__device__ __forceinline__ void emit_incr(double dvs, int ko, double obs, const Consts &K, int k0, double &ssq,
+__device__ __forceinline__ void emit_incr(double dvs, int ko, double obs, const Lane &L, int k0, double &ssq,
                                           double *acc_out, int64_t stride) {
-  if (WANT_ACC) acc_out[(int64_t)(k0 + ko) * stride] = dvs * K.cacc;
+  if (WANT_ACC) acc_out[(int64_t)(k0 + ko) * stride] = dvs * L.cv;
   if (WANT_SSQ) {
-    const double r = __builtin_fma(dvs, K.cacc, -obs);  // one rounding; identical with and without WANT_ACC
+    const double r = __builtin_fma(dvs, L.cv, -obs);  // one rounding; identical with and without WANT_ACC
     ssq = __builtin_fma(r, r, ssq);
   }
 }
@@ -473,11 +482,11 @@ __device__ __forceinline__ int integrate_pairs(const double *lds, const double *
       }
     }
     if (S1) {  // sample index == step index: no bookkeeping, and V is not carried at all
-      emit_incr<WANT_SSQ, WANT_ACC>(dv0, r, obs0, K, k0, ssq, acc_out, stride);
-      emit_incr<WANT_SSQ, WANT_ACC>(dv1, r + 1, obs1, K, k0, ssq, acc_out, stride);
+      emit_incr<WANT_SSQ, WANT_ACC>(dv0, r, obs0, L, k0, ssq, acc_out, stride);
+      emit_incr<WANT_SSQ, WANT_ACC>(dv1, r + 1, obs1, L, k0, ssq, acc_out, stride);
     } else {
-      const double vmid = __builtin_fma(K.h6, dv0, save.V);
-      s.V = __builtin_fma(K.h6, dv1, vmid);
+      const double vmid = __builtin_fma(L.h6v, dv0, save.V);
+      s.V = __builtin_fma(L.h6v, dv1, vmid);
       if (++em.phase == K.S) { em.phase = 0; emit_sample<WANT_SSQ, WANT_ACC>(vmid, em, obs0, K, k0, ssq, acc_out, stride); }
       if (++em.phase == K.S) { em.phase = 0; emit_sample<WANT_SSQ, WANT_ACC>(s.V, em, obs0, K, k0, ssq, acc_out, stride); }
     }
@@ -528,13 +537,13 @@ __device__ __forceinline__ int integrate_multi(const double *lds, const double *
     }
     if (S1) {
 #pragma unroll
-      for (int j = 0; j < NU; ++j) emit_incr<WANT_SSQ, WANT_ACC>(dv[j], r + j, obs[j], K, k0, ssq, acc_out, stride);
+      for (int j = 0; j < NU; ++j) emit_incr<WANT_SSQ, WANT_ACC>(dv[j], r + j, obs[j], L, k0, ssq, acc_out, stride);
     } else {
       int used = 0;  // wave-uniform: every lane emits the same samples
       s.V = save.V;
 #pragma unroll
       for (int j = 0; j < NU; ++j) {
-        s.V = __builtin_fma(K.h6, dv[j], s.V);
+        s.V = __builtin_fma(L.h6v, dv[j], s.V);
         if (++em.phase == K.S) {
           em.phase = 0;
           double o = obs[0];
@@ -598,9 +607,9 @@ __device__ __forceinline__ void integrate_tiers(const double *lds, const double 
       eval_full(s.ms, s.x, L, K, s.w, s.rx);
     }
     if (S1) {
-      emit_incr<WANT_SSQ, WANT_ACC>(dv, kn - 1, obs, K, k0, ssq, acc_out, stride);
+      emit_incr<WANT_SSQ, WANT_ACC>(dv, kn - 1, obs, L, k0, ssq, acc_out, stride);
     } else {
-      s.V = __builtin_fma(K.h6, dv, s.V);
+      s.V = __builtin_fma(L.h6v, dv, s.V);
       emit_at<WANT_SSQ, WANT_ACC>(s.V, em.vprev, kn - 1, obs, K, k0, ssq, acc_out, stride);
     }
   }
