@@ -56,7 +56,14 @@ enum Mode : int { RK4_F64 = 0, RK4_F32 = 1, DOP853 = 2 };  // how the ODE is int
 constexpr int kMaxBlock = 256;           // 4 waves: one per SIMD of a CU
 // Register budget of the RK4 sampler kernel: at least this many workgroups per CU, i.e. waves per SIMD (2 => at most
 // 256 of the 512 unified registers per lane).  cfg2 runs 4 waves per SIMD worth of chains, so a kernel that drifts
-// above 256 registers would run it in four rounds instead of two.  The DOP853 mode (12 stage vectors) is not bounded.
+// above 256 registers would run it in four rounds instead of two.  The DOP853 sampler (12 stage vectors) is held to the
+// same budget: unbounded it took 300 registers (256 + 44 AGPRs) and ran ONE wave per SIMD whatever the chain count, its
+// fp64 pipe 61 % busy behind 248 scalar instructions per interval (profiles/r02/cfg1_dop853_v19_pmc.json); at 256 registers
+// (188 B of scratch per lane) two waves share a SIMD: 2.93e10 -> 3.90e10 at 262 144 chains, 2.89e10 -> 3.64e10 at
+// 131 072, -0.8 % at 65 536 chains, where there is only one wave per SIMD to begin with (profiles/r02/dop853_occupancy_ab.log).
+#ifndef RSF_DP_MIN_BLOCKS
+#define RSF_DP_MIN_BLOCKS 2
+#endif
 #ifndef RSF_MIN_BLOCKS
 #define RSF_MIN_BLOCKS 2
 #endif
@@ -283,7 +290,7 @@ struct McmcArgs {
 };
 
 template <int D, bool DAMP, bool REPLAY, int MODE>
-__global__ void __launch_bounds__(kMaxBlock, MODE == DOP853 ? 1 : RSF_MIN_BLOCKS) mcmc_kernel(Consts K, McmcArgs A) {
+__global__ void __launch_bounds__(kMaxBlock, MODE == DOP853 ? RSF_DP_MIN_BLOCKS : RSF_MIN_BLOCKS) mcmc_kernel(Consts K, McmcArgs A) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   rsf::select_group(K);
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;

@@ -699,6 +699,28 @@ def test_float32_solve_tolerance(pkg, oracle_mod):
                 assert abs(out["f32"][2] - out["f64"][2]) < 0.05
 
 
+def test_float32_tolerance_at_config5_shape():
+    """BASELINE configs[4] per-GPU shard (131 072 chains, nsteps 4000, joint (Dc, a, b)) in BOTH precisions, same seeds —
+    tools/fp32_sweep_cfg5.py with a shorter sampler run.  Bands (profiles/r02/fp32_sweep_cfg5.json holds the 400-iteration
+    numbers): relative |SSq32 - SSq64| <= 1e-3 on every lane; posterior mean / std of each parameter move by less than
+    0.02 / 0.02 float64 posterior standard deviations; acceptance rates within 0.01."""
+    import os
+    import sys
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import fp32_sweep_cfg5
+
+    out = fp32_sweep_cfg5.sweep(iters=60)
+    assert out["shape"] == {"chains": 131072, "nsteps": 4000, "n_params": 3, "iters": 60}
+    assert out["ssq"]["nonfinite_f64"] == out["ssq"]["nonfinite_f32"] == 0 and out["ssq"]["lanes"] == 131072
+    assert out["ssq"]["rel_max"] < 1e-3 and out["ssq"]["rel_median"] < 2e-5, out["ssq"]
+    post = out["posterior"]
+    assert max(post["drift_in_units_of_f64_posterior_std"]["mean"]) < 0.02, post
+    assert max(post["drift_in_units_of_f64_posterior_std"]["std"]) < 0.02, post
+    assert post["accept_diff"] < 0.01 and 0.05 < post["float64"]["accept"] < 0.95
+    assert post["float64"]["nonfinite"] == 0 and post["float32"]["nonfinite"] == 0
+
+
 def test_replay_of_reference_variates(gpu_engine, golden, oracle_mod):
     """The reference's own recorded chain (tests/golden/replay_*.npz): feeding the GPU kernel the variates the
     reference consumed reproduces its accept decisions and samples up to the RK4-vs-dop853 difference."""
