@@ -61,6 +61,9 @@ constexpr int kMaxBlock = 256;           // 4 waves: one per SIMD of a CU
 // fp64 pipe 61 % busy behind 248 scalar instructions per interval (profiles/r02/cfg1_dop853_v19_pmc.json); at 256 registers
 // (188 B of scratch per lane) two waves share a SIMD: 2.93e10 -> 3.90e10 at 262 144 chains, 2.89e10 -> 3.64e10 at
 // 131 072, -0.8 % at 65 536 chains, where there is only one wave per SIMD to begin with (profiles/r02/dop853_occupancy_ab.log).
+#ifndef RSF_D3_TRIP
+#define RSF_D3_TRIP 1  // three-parameter sampler: TIGHT loop trips of RSF_D3_TRIP * RSF_TIGHT_UNROLL steps (the one-parameter sampler: 2 *)
+#endif
 #ifndef RSF_DP_MIN_BLOCKS
 #define RSF_DP_MIN_BLOCKS 2
 #endif
@@ -304,6 +307,11 @@ __global__ void __launch_bounds__(kMaxBlock, MODE == DOP853 ? RSF_DP_MIN_BLOCKS 
   for (int p = 0; p < D; ++p) q[p] = 1.0;
 #pragma unroll
   for (int e = 0; e < D * D; ++e) V[e] = 0.0;
+  // adaptation window (shifted sums over the last adapt_interval samples): 3 + 3 + 9 doubles for D = 3 — thirty registers
+  // that would stay live across the forward solve, where the register budget is spent on the integrator (the compiler used
+  // to spill some of them: 56-124 B of scratch per lane).  For D = 3 the window therefore lives in its HBM arrays and is
+  // read-modified-written once per proposal (30 accesses against 4000 RK4 steps); D = 1 keeps its three values in registers.
+  constexpr bool kWinRegs = D == 1;
   double wr[D], ws[D], wq[D * D];
   int32_t wn = 0;
   if (valid) {
@@ -314,13 +322,21 @@ __global__ void __launch_bounds__(kMaxBlock, MODE == DOP853 ? RSF_DP_MIN_BLOCKS 
     ssq = A.ssq[i];
     std2 = A.std2[i];
   }
-  if (A.adapt_mode != RSF_ADAPT_NONE && valid) {
+  auto load_window = [&]() {
 #pragma unroll
     for (int p = 0; p < D; ++p) { wr[p] = A.wref[i * D + p]; ws[p] = A.wsum[i * D + p]; }
 #pragma unroll
     for (int e = 0; e < D * D; ++e) wq[e] = A.wsq[i * D * D + e];
     wn = A.wn[i];
-  }
+  };
+  auto store_window = [&]() {
+#pragma unroll
+    for (int p = 0; p < D; ++p) { A.wref[i * D + p] = wr[p]; A.wsum[i * D + p] = ws[p]; }
+#pragma unroll
+    for (int e = 0; e < D * D; ++e) A.wsq[i * D * D + e] = wq[e];
+    A.wn[i] = wn;
+  };
+  if (kWinRegs && A.adapt_mode != RSF_ADAPT_NONE && valid) load_window();
   uint32_t n_acc = 0, n_eval = 0, n_nonfinite = 0;
 
   float *lds32 = reinterpret_cast<float *>(lds);
@@ -368,7 +384,7 @@ __global__ void __launch_bounds__(kMaxBlock, MODE == DOP853 ? RSF_DP_MIN_BLOCKS 
     if (!resident || __any(inb)) {
       if constexpr (MODE == RK4_F32) ssqn = rsf::f32::solve32<DAMP, true, false>(lds32, K, resident, inb, qn[0], an, bn, nullptr, 0);
       else if constexpr (MODE == DOP853) ssqn = rsf::dp::solve<DAMP, true, false>(lds, K, resident, inb, qn[0], an, bn, nullptr, 0);
-      else ssqn = rsf::solve<DAMP, true, false, (D == 1 ? 2 : 1) * RSF_TIGHT_UNROLL>(lds, K, resident, inb, qn[0], an, bn, nullptr, 0);
+      else ssqn = rsf::solve<DAMP, true, false, (D == 1 ? 2 : RSF_D3_TRIP) * RSF_TIGHT_UNROLL>(lds, K, resident, inb, qn[0], an, bn, nullptr, 0);
     }
     // ---- accept / reject, MCMC.py:327-333 ----
     bool accept = false;
@@ -408,6 +424,7 @@ __global__ void __launch_bounds__(kMaxBlock, MODE == DOP853 ? RSF_DP_MIN_BLOCKS 
     }
     // ---- adaptation, MCMC.py:200-204, 523-527 ----
     if (A.adapt_mode != RSF_ADAPT_NONE && valid) {
+      if (!kWinRegs) load_window();
 #pragma unroll
       for (int p = 0; p < D; ++p) {
         ws[p] += q[p] - wr[p];
@@ -441,6 +458,7 @@ __global__ void __launch_bounds__(kMaxBlock, MODE == DOP853 ? RSF_DP_MIN_BLOCKS 
 #pragma unroll
         for (int e = 0; e < D * D; ++e) wq[e] = 0.0;
       }
+      if (!kWinRegs) store_window();
     }
   }
 
@@ -451,13 +469,7 @@ __global__ void __launch_bounds__(kMaxBlock, MODE == DOP853 ? RSF_DP_MIN_BLOCKS 
     for (int e = 0; e < D * D; ++e) A.V[i * D * D + e] = V[e];
     A.ssq[i] = ssq;
     A.std2[i] = std2;
-    if (A.adapt_mode != RSF_ADAPT_NONE) {
-#pragma unroll
-      for (int p = 0; p < D; ++p) { A.wref[i * D + p] = wr[p]; A.wsum[i * D + p] = ws[p]; }
-#pragma unroll
-      for (int e = 0; e < D * D; ++e) A.wsq[i * D * D + e] = wq[e];
-      A.wn[i] = wn;
-    }
+    if (kWinRegs && A.adapt_mode != RSF_ADAPT_NONE) store_window();
   }
   // statistics: wave shuffle reduction, one atomic per wave and counter
   const unsigned long long s0 = rsf::wave_sum(n_acc), s1 = rsf::wave_sum(n_eval), s2 = rsf::wave_sum(n_nonfinite);
