@@ -13,14 +13,14 @@ RateStateModel.py:392), so `np.random.seed(s)` selects the same chain the refere
 `sample_batched()` (additive) runs many independent chains per launch with the on-device
 Philox stream and is the throughput path.
 """
-import warnings
-
 import numpy as np
 
 if __package__:
+    from . import _figures
     from ._abi import ADAPT_MODES
     from .engine import Engine
 else:  # flat layout: this directory on sys.path, the reference's own import style (main.py:44-46)
+    import _figures
     from _abi import ADAPT_MODES
     from engine import Engine
 
@@ -222,27 +222,8 @@ class MCMC:
 
     # ---- visualisation (off the hot path; degrades gracefully) --------------------------
     def _animate(self, qparams):
-        try:
-            import matplotlib.pyplot as plt
-            from matplotlib.animation import FuncAnimation
-
-            fig, ax = plt.subplots()
-            (line,) = ax.plot([], [], lw=2)
-            ax.set_title(f"MCMC Sampling Evolution for dc = {self.dc_true:.2f} as True value")
-            ax.set_xlabel("Sample Index")
-            ax.set_ylabel("Sample Value")
-            ax.set_xlim(0, self.nsamples)
-            ax.set_ylim(np.min(qparams) - 1, np.max(qparams) + 1)
-
-            def update(frame):
-                line.set_data(np.arange(frame), qparams[0, :frame])
-                return (line,)
-
-            anim = FuncAnimation(fig, update, frames=self.nsamples, blit=True)
-            anim.save(f"mcmc_animation_dc_{self.dc_true:.2f}.mp4", fps=30, writer="ffmpeg")
-            plt.close(fig)
-        except Exception as ex:  # no ffmpeg / no display: the samples are still returned
-            warnings.warn(f"MCMC animation skipped: {ex}")
+        _figures.chain_movie(qparams[0], f"MCMC Sampling Evolution for dc = {self.dc_true:.2f} as True value",
+                             f"mcmc_animation_dc_{self.dc_true:.2f}.mp4")
 
 
 assert set(ADAPT_MODES) == {"none", "reference_dict", "am"}

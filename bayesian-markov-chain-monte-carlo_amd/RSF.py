@@ -9,15 +9,15 @@ the JSON helpers are imported under their own names (the reference shadows them 
 ones), the MySQL helpers are imported lazily, and a missing ffmpeg/display only skips figures.
 """
 import time
-import warnings
 
 import numpy as np
 
 if __package__:
-    from . import json_save_load
+    from . import _figures, json_save_load
     from .engine import Engine
     from .MCMC import MCMC, PosteriorPool
 else:  # flat layout: this directory on sys.path, the reference's own import style (main.py:44-46)
+    import _figures
     import json_save_load
     from engine import Engine
     from MCMC import MCMC, PosteriorPool
@@ -66,21 +66,8 @@ class RSF:
         return acc_appended_noise
 
     def plot_time_series(self, time, acceleration):
-        if not self.plotfigs:
-            return
-        try:
-            import matplotlib.pyplot as plt
-
-            plt.figure()
-            plt.title(f"$d_c$={self.model.Dc} $\\mu m$ RSF solution")
-            plt.plot(time, acceleration, linewidth=1.0, label="True")
-            plt.xlim(self.model.t_start - 2.0, self.model.t_final)
-            plt.xlabel("Time (sec)")
-            plt.ylabel("Acceleration $(\\mu m/s^2)$")
-            plt.grid(True)
-            plt.legend()
-        except Exception as ex:
-            warnings.warn(f"time-series figure skipped: {ex}")
+        if self.plotfigs:
+            _figures.series_figure(time, acceleration, self.model.Dc, self.model.t_start, self.model.t_final)
 
     def prepare_data(self, data):
         if self.format == "json":
@@ -94,26 +81,9 @@ class RSF:
         return data
 
     def plot_dist(self, qparams, dc):
-        try:
-            import matplotlib.pyplot as plt
-            from scipy.stats import gaussian_kde
-
-            fig, axes = plt.subplots(1, 2, gridspec_kw={"width_ratios": [0.7, 0.15], "wspace": 0.15})
-            fig.suptitle(f"$d_c={dc:.2f}\\,\\mu m$ with {self.format} formatting", fontsize=10)
-            axes[0].plot(qparams[0, :], "b-", linewidth=1.0)
-            axes[0].set_ylabel("$d_c$", fontsize=10)
-            axes[0].set_xlabel("Sample number")
-            axes[0].set_xlim(0, qparams.shape[1])
-            grid = np.linspace(*axes[0].get_ylim(), 1000)
-            pdf = gaussian_kde(qparams[0, :]).pdf(grid)
-            axes[1].plot(pdf, grid, "b-", linewidth=1.0)
-            axes[1].fill_betweenx(grid, pdf, np.zeros(grid.shape), alpha=0.3)
-            axes[1].set_xlim(0, None)
-            axes[1].set_xlabel("Prob. density")
-            axes[1].get_yaxis().set_visible(False)
-            axes[1].get_xaxis().set_ticks([])
-        except Exception as ex:  # e.g. a chain that never moved makes the KDE singular
-            warnings.warn(f"posterior figure skipped: {ex}")
+        """Kept samples beside their kernel density (RSF.py:717-746); the density is the device KDE of the pooled draws."""
+        kde = self.model.engine().pool_kde
+        return _figures.trace_with_density(qparams[0, :], f"$d_c={dc:.2f}\\,\\mu m$ with {self.format} formatting", kde)
 
     def perform_sampling_and_plotting(self, data, dc, nsamples, model_lstm):
         index = np.where(self.dc_list == dc)[0][0] if dc in self.dc_list else -1

@@ -284,3 +284,29 @@ def test_reference_written_json_files(pkg, golden, tmp_path):
     np.testing.assert_array_equal(arr, np.random.default_rng(3).standard_normal(12) * 1e-3)
     d = J.load_object(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_written_dict.json"))
     assert d["grid"].shape == (2, 3) and d["ints"].tolist() == [0, 1, 2, 3] and d["meta"] == {"dc": 1000.0, "n": 12, "tags": ["a", "b"]}
+
+
+def test_posterior_figure_uses_the_engine_kde(pkg, model, monkeypatch):
+    """RSF.plot_dist (RSF.py:717-746): trace panel + density panel; the density drawn is the engine's KDE of the kept
+    samples (here the oracle engine's; on a GPU box the device KDE) and equals scipy.stats.gaussian_kde on the same grid."""
+    pytest.importorskip("matplotlib")
+    monkeypatch.setenv("MPLBACKEND", "Agg")
+    import matplotlib
+
+    matplotlib.use("Agg", force=True)
+    from scipy.stats import gaussian_kde
+
+    problem = pkg.RSF(number_slip_values=1, lowest_slip_value=1000.0, largest_slip_value=1000.0, qstart=1000.0)
+    problem.model, problem.format = model, "json"
+    q = np.random.default_rng(3).normal(1000.0, 40.0, (1, 300))
+    fig = problem.plot_dist(q, 1000.0)
+    assert fig is not None and len(fig.axes) == 2
+    pdf, grid = fig.axes[1].lines[0].get_data()
+    assert len(grid) == 1000
+    np.testing.assert_allclose(pdf, gaussian_kde(q[0]).pdf(grid), rtol=1e-9, atol=1e-300)
+    np.testing.assert_array_equal(fig.axes[0].lines[0].get_ydata(), q[0])
+    with pytest.warns(UserWarning, match="posterior figure skipped"):   # a chain that never moved: no density, no crash
+        assert problem.plot_dist(np.full((1, 50), 1000.0), 1000.0) is None
+    import matplotlib.pyplot as plt
+
+    plt.close("all")
