@@ -168,8 +168,8 @@ __device__ __forceinline__ void eval_full(double ms, double x, const Lane &L, co
 // dlt = dk - (b/a) log1p(rho), dk = dmu/a = kia*dms:   w' = w exp(dlt),   1/x' = (1/x)/(1 + rho),
 // by short series — the same function of (ms', x') to rounding inside the tier's guard region:
 //   tier     |rho| <   |dlt| <   log1p to     expm1 to       1/x'                              truncation
-//   TIGHT    2^-20     2^-9      rho^2/2      dlt^5/120      1 - rho + rho^2 (no Newton step)  < 3e-19, rho^3 < 2^-60
-//            (its two half-step stages: |dlt| < 2^-10 and expm1 to dlt^4/24, truncation < 8e-18 relative)
+//   TIGHT    2^-20     2^-9      rho^2/2      dlt^4/24       1 - rho + rho^2 (no Newton step)  rho^3 < 2^-60; expm1: < 2.4e-16 at the
+//            (its two half-step stages: |dlt| < 2^-10, truncation < 8e-18 relative)              guard's edge (1 ulp), 8e-18 at |dlt| = 1e-3
 //   NARROW   2^-9      2^-6      rho^6/6      dlt^7/5040     2nd-order start + 1 Newton step   < 1e-19, rho^6 < 2^-54
 //   WIDE     2^-7      2^-6      rho^7/7      dlt^7/5040     1st-order start + 2 Newton steps  < 1e-19, rho^8 < 2^-56
 // Guard tracks the largest |rho| / |dlt| seen since it was last reset — through the HIGH WORD of each double read as
@@ -242,7 +242,16 @@ __device__ __forceinline__ void eval_incr(double kf, double dms_dt, double R, do
     p = __builtin_fma(p, rho, 1.0);
   }
   const double dlt = __builtin_fma(-(L.boa * rho), p, kf * dms_dt);  // d1 -> rho -> p -> dlt: three deep
-  constexpr bool kShort = T == TIGHT && HALF;  // half-step stage of the TIGHT tier: |dlt| < 2^-10, series to dlt^4/24
+  // TIGHT: expm1 to dlt^4/24 at every stage.  Half-step stages are held to |dlt| < 2^-10 (truncation dlt^5/120 < 7.4e-18 relative);
+  // the full-step stage and the step's end point to |dlt| < 2^-9, where the same series truncates at < 2^-45/120 = 2.4e-16 —
+  // one ulp at the guard's edge, 8e-18 at the |dlt| ~ 1e-3 of Dc ~ 1000 — which saves their sixth-degree term
+  // (-DRSF_TIGHT_LONG_FULL keeps it: the v20 arithmetic, for A/B measurement).
+#ifdef RSF_TIGHT_LONG_FULL
+  constexpr bool kShortSeries = T == TIGHT && HALF;
+#else
+  constexpr bool kShortSeries = T == TIGHT;
+#endif
+  constexpr bool kShort = T == TIGHT && HALF;  // guard accumulator of the half-step stages (2^-10)
 #ifdef RSF_GUARD_F64
   if (kShort) g.dlt_h = __builtin_fmax(g.dlt_h, __builtin_fabs(dlt));
   else g.dlt = __builtin_fmax(g.dlt, __builtin_fabs(dlt));
@@ -251,7 +260,7 @@ __device__ __forceinline__ void eval_incr(double kf, double dms_dt, double R, do
   else g.dlt = __builtin_fmaxf(g.dlt, __builtin_fabsf(hi_as_float(dlt)));
 #endif
   double e;
-  if (kShort) {
+  if (kShortSeries) {
     e = L.c_em1h;
   } else {
     if (T == TIGHT) {
