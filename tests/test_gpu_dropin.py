@@ -239,3 +239,64 @@ def test_inference_slices_and_chains_equal_the_reference(pkg, golden, tmp_path, 
     for i, dc in enumerate(g["dc_list"]):
         np.testing.assert_allclose(problem.posteriors[float(dc)], g[f"qparams_{i}"], rtol=2e-8, err_msg=f"dc {dc}")
     assert not np.allclose(g["qparams_0"], g["qparams_1"], rtol=1e-2) and not np.allclose(g["qparams_1"], g["qparams_2"], rtol=1e-2)
+
+
+def test_config3_shard_at_full_size_with_rccl_pool(pkg):
+    """BASELINE configs[3] as far as one GPU goes: ONE rank's shard in its stated size — 262 144 chains (2 097 152 / 8),
+    1000 proposals each, nsteps 500, post-burn-in pool of 501 draws per chain = 1.05 GB — through `dist.run_sharded`
+    (the multi-GPU driver: shard by global chain id, sample, one all-gather of the kept block) on a real NCCL/RCCL
+    process group of world size 1, then the same pool once more through the C ABI's own RCCL communicator.  Checked:
+    the gathered pool IS the shard's kept block (bit for bit, both routes); shifting the shard to the chain-id range rank
+    3 of 8 would own changes the draws (the RNG is keyed by the global id); posterior moments are sane.  The 8-rank run
+    itself needs the driver's node."""
+    import socket
+
+    import torch
+    import torch.distributed as dist
+
+    from bayesian_markov_chain_monte_carlo_amd import dist as rdist
+
+    C, n_iters, nburn = 262144, 1000, 500
+    model = pkg.RateStateModel(number_time_steps=500)
+    with pkg.Engine(mem="host") as e:
+        e.set_model(model, 1)
+        from conftest import synthetic_data
+
+        data = synthetic_data(e)
+    q0 = np.full((C, 1), 1000.0)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+    try:
+        pool, stats = rdist.run_sharded(lambda: pkg.Engine(mem="device"), model, 1, data, q0, [0.0], [1.0e4], n_iters, nburn,
+                                        seed=2025, mcmc_kwargs=dict(prior_len=3))
+        torch.cuda.synchronize()
+        assert pool.shape == (n_iters + 1 - nburn, C, 1) and pool.is_cuda       # 501 kept rows x 262 144 chains: 1.05 GB
+        assert stats["iters_done"] == n_iters and stats["evaluated"] == stats["iters_done"] * C and stats["nonfinite"] == 0
+        mean, std = float(pool.mean()), float(pool.std())
+        # one noise realisation (|acc| N(0,1), seed 2025) puts the posterior at 1040 +- 51 for nsteps 500; the reference's own
+        # single-chain run on ITS realisation: 990 +- 43 (tests/golden/config1.json)
+        assert abs(mean - 1000.0) < 100.0 and 20.0 < std < 80.0, (mean, std)
+        assert 0.5 < stats["accepted"] / (n_iters * C) < 0.9
+        # the same shard again by hand: the pool is exactly the kept block of the shard's trace
+        with pkg.Engine(mem="device") as e:
+            e.set_model(model, 1)
+            e.mcmc_init(q0, data, [0.0], [1.0e4], seed=2025, chain_offset=0, prior_len=3)
+            tq, _, _ = e.mcmc_run(n_iters, traces=("q",))
+            e.sync()
+            assert torch.equal(pool, tq[nburn - 1:])
+            # ... and through the C ABI (rsf_comm_init + rsf_pool_allgather: the library's own RCCL communicator)
+            rdist.comm_init_from_process_group(e)
+            out = e.pool_allgather(tq[nburn - 1:].contiguous())
+            e.sync()
+            assert out.shape == (1, n_iters + 1 - nburn, C, 1) and torch.equal(out[0], pool)
+            e.comm_destroy()
+            del out
+            # rank 3 of 8 would own global chains [3C, 4C): different draws from the same start
+            e.mcmc_init(q0[:4096], data, [0.0], [1.0e4], seed=2025, chain_offset=3 * C, prior_len=3)
+            t3, _, _ = e.mcmc_run(50, traces=("q",))
+            e.sync()
+            assert not torch.equal(t3, tq[:50, :4096])
+    finally:
+        dist.destroy_process_group()
