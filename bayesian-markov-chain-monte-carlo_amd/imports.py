@@ -13,9 +13,12 @@ from numpy import exp, log, sin  # noqa: F401
 from scipy import integrate  # noqa: F401
 from scipy.stats import gamma, gaussian_kde  # noqa: F401
 
-for _optional in ("import matplotlib.pyplot as plt", "from matplotlib.animation import FuncAnimation", "import mysql.connector"):
-    try:
-        exec(_optional)
-    except Exception:  # absent or unusable on this host: only plotting / MySQL persistence need them
-        pass
-del _optional
+try:  # figures only (RSF.plot_*, MCMC animation); absent or unusable => those are skipped with a warning
+    import matplotlib.pyplot as plt  # noqa: F401
+    from matplotlib.animation import FuncAnimation  # noqa: F401
+except Exception:
+    pass
+try:  # MySQL persistence only (out of scope here, RSF.prepare_data raises for it); the reference hard-imports this
+    import mysql.connector  # noqa: F401
+except Exception:
+    pass
