@@ -9,6 +9,7 @@ The class is library-agnostic (`lib` is any handle typed by _abi.bind) so the te
 drive the CPU oracle through the very same code; the product always passes _abi.load().
 """
 import ctypes
+import os
 
 import numpy as np
 
@@ -57,6 +58,12 @@ class Engine:
         if lib is None:
             lib = _abi.load()
             _abi.require_device(lib)
+        elif lib.rsf_backend() != b"hip-gfx950" and os.environ.get("RSF_ALLOW_CHECKER_ENGINE") != "1":
+            # `lib` exists so that the test-suite can drive the CPU oracle through this very class; nothing in the product may
+            # end up on it by accident: a non-HIP library is refused unless the caller has declared itself a checker
+            # (tests/conftest.py, __graft_entry__.smoke() and bench.py's cpu_baseline leg set the variable)
+            raise _abi.RsfError(-2, f"Engine(lib=...) was handed the {lib.rsf_backend().decode()!r} library: the product runs on "
+                                    "csrc/librsf_hip.so only (no CPU fallback); checkers set RSF_ALLOW_CHECKER_ENGINE=1")
         self.lib = lib
         self.mem = mem
         self._torch = None

@@ -6,6 +6,7 @@ import sys
 import numpy as np
 import pytest
 
+os.environ["RSF_ALLOW_CHECKER_ENGINE"] = "1"  # the test-suite is the checker: it may bind Engine to the CPU oracle
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 for p in (ROOT, os.path.join(ROOT, "oracle")):

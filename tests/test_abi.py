@@ -159,3 +159,12 @@ def test_pool_collectives_call_order_and_single_rank(pkg, oracle_lib):
         e.comm_destroy()
         with pytest.raises(pkg.RsfError, match="comm_init"):
             e.pool_allreduce_sum(y)
+
+
+def test_engine_refuses_the_checker_library_unless_declared(pkg, oracle_lib, monkeypatch):
+    """Engine(lib=...) exists for the test-suite; a non-HIP library handed to it by accident must not run anything."""
+    monkeypatch.delenv("RSF_ALLOW_CHECKER_ENGINE", raising=False)
+    with pytest.raises(pkg.RsfError, match="no CPU fallback"):
+        pkg.Engine(lib=oracle_lib)
+    monkeypatch.setenv("RSF_ALLOW_CHECKER_ENGINE", "1")
+    pkg.Engine(lib=oracle_lib).close()
