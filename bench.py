@@ -52,6 +52,8 @@ PROPOSAL_STD = [20.0, 1.0e-4, 1.0e-4]          # explicit proposal covariance fo
 FLOPS_PER_RK4_STEP = 152.0       # 4 RHS x 27 + RK4 combine 39 + observation/SSq 5
 PEAK_HBM_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 PEAK_FP64_VALU_TFLOPS = 78.6     # 256 CU x 4 SIMD x 16 fp64 FMA lanes x 2 flop x 2.4 GHz
+SUSTAINED_FMA_TFLOPS = 70.0      # what a pure, fully occupied v_fma_f64 stream holds on this part for ~1 s (the power manager settles at
+                                 # ~2.14 GHz under it): tools/peak_fp64.hip -> profiles/r02/peak_fp64.log (61.3 at two waves per SIMD)
 
 
 def synthetic_problem(nsteps):
@@ -260,6 +262,11 @@ def roofline_views(workload, custom, C, ips, nout, stats, kernel_ms, d=1, mode="
             "flops_per_rk4_step": FLOPS_PER_RK4_STEP, "rk4_steps_per_s": rk4_steps_per_launch / (kernel_ms * 1e-3),
             "valu_insts_per_rk4_step": pmc.get("valu_insts_per_rk4_step"), "pipe_busy": pmc.get("pipe_busy"),
             "pmc_source": pmc.get("pmc_source"),
+            "peak_sustained": SUSTAINED_FMA_TFLOPS, "frac_of_sustained": tflops / SUSTAINED_FMA_TFLOPS,
+            "issue_rate_vs_pure_fma_stream": (pmc["valu_insts_per_rk4_step"] * rk4_steps_per_launch / (kernel_ms * 1e-3) * 2.0 / 1e12
+                                              / SUSTAINED_FMA_TFLOPS) if pmc.get("valu_insts_per_rk4_step") else None,
+            "peak_sustained_source": "measured: pure v_fma_f64 stream, 8 waves/SIMD, 1 s (tools/peak_fp64.hip, profiles/r02/peak_fp64.log); "
+                                     "issue_rate_vs_pure_fma_stream = this kernel's per-lane VALU instructions/s (PMC count x steps/s; x 2 flop) over that stream's",
             "note": "fp64 VALU issue binds (no MFMA: elementwise ODE recurrence); peak = 256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz; "
                     "pipe_busy = 4 cycles x SQ_INSTS_VALU / SIMDs / GRBM_GUI_ACTIVE is the utilisation figure, frac the nominal-flop one"}
     hbm = {"bound": "hbm", "achieved": hbm_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": hbm_gbs / PEAK_HBM_GBS,
