@@ -6,7 +6,7 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 for ips in 10 100; do
   OUT=gpurun_out/clock_$ips
   rm -rf $OUT
-  rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT -- python3 bench.py --no-cpu-baseline --iters-per-step $ips --steps 10 --warmup 2 > $OUT.log 2>&1
+  rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT -- python3 bench.py --workload cfg1 --no-also --no-cpu-baseline --iters-per-step $ips --steps 10 --warmup 2 > $OUT.log 2>&1
 done
 python3 - <<'PY'
 import csv, glob
