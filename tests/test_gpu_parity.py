@@ -744,13 +744,18 @@ def test_replay_of_reference_variates(gpu_engine, golden, oracle_mod):
         np.testing.assert_allclose(ts[nb - 1:, 0], g["std2_kept"], rtol=1e-5)
 
 
-@pytest.mark.parametrize("C,n,d,iters", [(65536, 500, 1, 5), (262144, 2000, 1, 2), (131072, 4000, 3, 1)])
-def test_full_size_configs_against_the_oracle(pkg, oracle_lib, oracle_mod, C, n, d, iters):
+@pytest.mark.parametrize("C,n,d,iters,variant", [(65536, 500, 1, 5, "rk4"), (262144, 2000, 1, 2, "rk4"), (131072, 4000, 3, 1, "rk4"),
+                                                 (65536, 500, 1, 3, "rk4_substeps2"), (65536, 500, 1, 2, "dop853")])
+def test_full_size_configs_against_the_oracle(pkg, oracle_lib, oracle_mod, C, n, d, iters, variant):
     """Tier 1 AT the BASELINE shapes (configs[1], configs[2], one GPU's share of configs[4]): every chain of the full
     grid, HIP sampler vs the CPU oracle on the same Philox stream — accept flags, samples and sigma^2 of all C chains
     (rtol 1e-9; a fork only where proven a near-tie), plus SSq / log-likelihood of the end state.  The oracle needs
-    about 1-25 s of the host's cores for each (OpenMP over chains)."""
-    m = _models(oracle_mod, n)
+    about 1-25 s of the host's cores for each (OpenMP over chains).  Variants at the configs[1] shape: two RK4 steps per output
+    interval, and the reference's own DOP853 scheme (the register-bounded sampler kernel with its spills, at scale)."""
+    S = 2 if variant == "rk4_substeps2" else 1
+    m = _models(oracle_mod, n, S)
+    if variant == "dop853":
+        m.integrator = "dop853"
     rng = np.random.default_rng(C + n)
     start = np.array([1000.0, 0.011, 0.014][:d])
     q0 = np.tile(start, (C, 1))
@@ -760,7 +765,7 @@ def test_full_size_configs_against_the_oracle(pkg, oracle_lib, oracle_mod, C, n,
     with pkg.Engine(mem="host") as gpu, pkg.Engine(lib=oracle_lib) as cpu:
         assert gpu.lib.rsf_backend() == b"hip-gfx950" and cpu.lib.rsf_backend() != b"hip-gfx950"
         for e in (gpu, cpu):
-            e.set_model(m, 1)
+            e.set_model(m, S)
         data = synthetic_data(cpu)
         for e in (gpu, cpu):
             e.mcmc_init(q0, data, lo, hi, **kw)
