@@ -99,6 +99,7 @@ PROTOTYPES = {
     "rsf_mcmc_stats": (c_int, [c_void_p, POINTER(c_int64), POINTER(c_int64), POINTER(c_int64), POINTER(c_int64)]),
     "rsf_pool_summary": (c_int, [c_void_p, c_int64, _P, c_int64, POINTER(c_double)]),
     "rsf_pool_kde": (c_int, [c_void_p, c_int64, _P, c_int64, c_int32, _P, c_double, _P]),
+    "rsf_pool_histogram": (c_int, [c_void_p, c_int64, _P, c_int64, c_int32, c_double, c_double, _P]),
     "rsf_comm_unique_id": (c_int, [POINTER(c_uint8)]),
     "rsf_comm_init": (c_int, [c_void_p, c_int32, c_int32, POINTER(c_uint8)]),
     "rsf_comm_destroy": (c_int, [c_void_p]),

@@ -514,6 +514,37 @@ pool_moments_kernel(int64_t n, const double *__restrict__ x, int64_t stride, dou
   }
 }
 
+// Fixed-bin histogram (rsf_pool_histogram): HBM-bound, one pass.  Every workgroup counts into an LDS copy of the bins
+// (ds_add_u32), then adds its non-empty bins to the global 64-bit counters — integer atomics, so the result does not
+// depend on the order of arrival.  Bin index = floor((x - lo) * scale), scale = nbins/(hi - lo) from the host: one
+// subtraction and one product, no contraction possible, hence bit-identical to the CPU restatement.
+constexpr int kHistMaxBins = 4096;
+
+__device__ __forceinline__ int hist_bin(double v, double lo, double hi, double scale, int nbins) {
+  if (v < lo) return 0;
+  if (!(v <= hi)) return nbins + 1;                      // above hi, or NaN
+  const int b = (int)floor((v - lo) * scale);
+  return 1 + (b < nbins ? b : nbins - 1);                // v == hi (or rounding at the upper edge) -> last bin
+}
+
+__global__ void __launch_bounds__(kMaxBlock)
+pool_hist_kernel(int64_t n, const double *__restrict__ x, int64_t stride, int nbins, double lo, double hi, double scale,
+                 unsigned long long *__restrict__ counts) {
+  extern __shared__ unsigned int hbins[];
+  for (int b = threadIdx.x; b < nbins + 2; b += blockDim.x) hbins[b] = 0u;
+  __syncthreads();
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    atomicAdd(&hbins[hist_bin(x[i * stride], lo, hi, scale, nbins)], 1u);
+  __syncthreads();
+  for (int b = threadIdx.x; b < nbins + 2; b += blockDim.x)
+    if (hbins[b]) atomicAdd(&counts[b], (unsigned long long)hbins[b]);
+}
+
+__global__ void __launch_bounds__(kMaxBlock) pool_hist_finish_kernel(int nb, const unsigned long long *__restrict__ counts, double *__restrict__ out) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b < nb) out[b] = (double)counts[b];
+}
+
 // Each workgroup owns a contiguous slice of the samples, streamed through LDS in tiles; every thread
 // accumulates the kernel sum of its grid points over the slice (LDS broadcast reads).  partial[block][m].
 constexpr int kKdeTile = 1024;
@@ -1359,6 +1390,29 @@ int rsf_pool_kde(rsf_ctx *c, int64_t n, const double *x, int64_t stride, int32_t
   hipLaunchKernelGGL(pool_kde_reduce_kernel, dim3((m + kMaxBlock - 1) / kMaxBlock), dim3(kMaxBlock), 0, c->stream, blocks, (int)m,
                      (const double *)ws.p, 1.0 / ((double)n * std::sqrt(2.0 * 3.14159265358979323846 * cov)), (double *)dd);
   if ((rc = copy_back(c, 2, density, (size_t)m * sizeof(double)))) return rc;
+  return finish(c);
+}
+
+int rsf_pool_histogram(rsf_ctx *c, int64_t n, const double *x, int64_t stride, int32_t nbins, double lo, double hi, double *counts) {
+  if (!c || !x || !counts || n < 1 || stride < 1 || nbins < 1 || nbins > kHistMaxBins || !(hi > lo) || !std::isfinite(hi - lo))
+    return fail(RSF_ERR_INVALID, "rsf_pool_histogram: bad argument (1 <= nbins <= %d, finite lo < hi)", kHistMaxBins);
+  DeviceGuard guard(c->device);
+  if (!guard.ok) return fail(RSF_ERR_DEVICE, "rsf_pool_histogram: cannot select device %d", c->device);
+  const void *dx;
+  void *dout;
+  int rc;
+  const int nb = nbins + 2;
+  if ((rc = stage_in(c, 0, x, (size_t)((n - 1) * stride + 1) * sizeof(double), &dx))) return rc;
+  if ((rc = stage_out(c, 2, counts, (size_t)nb * sizeof(double), &dout))) return rc;
+  DevBuf &ws = c->stage[7];
+  if ((rc = ensure(ws, (size_t)nb * sizeof(unsigned long long)))) return rc;
+  HIP_TRY(hipMemsetAsync(ws.p, 0, (size_t)nb * sizeof(unsigned long long), c->stream));
+  const int blocks = (int)std::min<int64_t>(kPoolBlocks, (n + kMaxBlock - 1) / kMaxBlock);
+  hipLaunchKernelGGL(pool_hist_kernel, dim3(blocks), dim3(kMaxBlock), (size_t)nb * sizeof(unsigned int), c->stream, n, (const double *)dx,
+                     stride, (int)nbins, lo, hi, (double)nbins / (hi - lo), (unsigned long long *)ws.p);
+  hipLaunchKernelGGL(pool_hist_finish_kernel, dim3((nb + kMaxBlock - 1) / kMaxBlock), dim3(kMaxBlock), 0, c->stream, nb,
+                     (const unsigned long long *)ws.p, (double *)dout);
+  if ((rc = copy_back(c, 2, counts, (size_t)nb * sizeof(double)))) return rc;
   return finish(c);
 }
 

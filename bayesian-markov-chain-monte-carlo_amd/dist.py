@@ -94,6 +94,19 @@ def allreduce_summary(local, group=None, device=None):
     return dict(n=N, mean=gmean, var=float(m2[0]) / (N - 1.0) if N > 1 else 0.0, min=float(lo[0]), max=float(hi[0]))
 
 
+def allreduce_histogram(counts, group=None, device=None):
+    """Summary path: per-rank `Engine.pool_histogram` counts (exact integers in float64) → the histogram of the union of all
+    ranks' draws, one all-reduce of nbins + 2 doubles (RCCL with backend "nccl", gloo in the CPU test-suite)."""
+    import torch
+    import torch.distributed as dist
+
+    t = counts.clone() if isinstance(counts, torch.Tensor) else torch.as_tensor(np.array(counts, dtype=np.float64))
+    if device is not None:
+        t = t.to(device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return t
+
+
 def pool_to_chain_major(pool):
     """(G, n_keep, C_local, d) → (n_keep, G*C_local, d): global chain id = g*C_local + c."""
     G, n, C, d = pool.shape

@@ -257,6 +257,16 @@ class Engine:
                                                    self._ptr(dens)))
         return dens
 
+    def pool_histogram(self, samples, nbins, lo, hi, param=0):
+        """numpy.histogram(samples, nbins, (lo, hi)) of parameter `param` over all pooled draws, plus the out-of-range counts:
+        → counts[nbins + 2] (float64 holding exact integers): [below lo, bin 0 .. bin nbins-1, above hi or NaN].  The summary path
+        of SURVEY §8e: a few KB per rank, summed across ranks with pool_allreduce_sum / dist.allreduce_histogram."""
+        x, n, d, p = self._column(samples, param)
+        counts = self._empty((int(nbins) + 2,))
+        _abi.check(self.lib, self.lib.rsf_pool_histogram(self._ctx, n, self._ptr(x) + 8 * p, d, int(nbins), float(lo), float(hi),
+                                                         self._ptr(counts)))
+        return counts
+
     # -- multi-GPU posterior pool through the C ABI (RCCL bound inside the library; SURVEY §8e) -----
     def comm_unique_id(self):
         """Rank 0: the 128-byte id every rank passes to comm_init (send it over any channel)."""

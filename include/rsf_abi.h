@@ -205,6 +205,15 @@ int rsf_pool_summary(rsf_ctx *ctx, int64_t n, const double *x, int64_t stride, d
 int rsf_pool_kde(rsf_ctx *ctx, int64_t n, const double *x, int64_t stride, int32_t m, const double *grid,
                  double bw_factor, double *density);
 
+/* Fixed-bin histogram of n samples x[i*stride] over [lo, hi] (the summary path of SURVEY §8e: a few KB per GPU that
+ * rsf_pool_allreduce_sum combines across ranks when the pool itself need not be materialised).  numpy.histogram
+ * semantics: nbins equal bins, bin i = [lo + i w, lo + (i+1) w) with w = (hi-lo)/nbins, the last bin closed at hi.
+ *   counts[0] = samples below lo, counts[1 .. nbins] = the bins, counts[nbins+1] = samples above hi or NaN.
+ * Counts are exact integers stored as doubles (so that the double all-reduce sums them exactly); `counts` follows the
+ * ctx mem_space; 1 <= nbins <= 4096. */
+int rsf_pool_histogram(rsf_ctx *ctx, int64_t n, const double *x, int64_t stride, int32_t nbins, double lo, double hi,
+                       double *counts);
+
 /* ---- multi-GPU posterior pool: one process per GPU, RCCL over xGMI -----------------
  * The reference runs its chains one after another in one process (RSF.py:1040-1046); here each rank
  * samples its own block of global chain ids with no exchange, and the kept rows are pooled ONCE.

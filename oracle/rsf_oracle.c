@@ -710,6 +710,24 @@ int rsf_pool_kde(rsf_ctx *c, int64_t n, const double *x, int64_t stride, int32_t
   return RSF_OK;
 }
 
+/* Fixed-bin histogram, numpy.histogram semantics (include/rsf_abi.h): counts[0] below lo, counts[1..nbins], counts[nbins+1]
+ * above hi or NaN.  Same index arithmetic as the device kernel: floor((x - lo) * (nbins/(hi - lo))). */
+int rsf_pool_histogram(rsf_ctx *c, int64_t n, const double *x, int64_t stride, int32_t nbins, double lo, double hi, double *counts) {
+  if (!c || !x || !counts || n < 1 || stride < 1 || nbins < 1 || nbins > 4096 || !(hi > lo) || !isfinite(hi - lo))
+    return fail(RSF_ERR_INVALID, "rsf_pool_histogram: bad argument (1 <= nbins <= 4096, finite lo < hi)");
+  const double scale = (double)nbins / (hi - lo);
+  for (int32_t b = 0; b < nbins + 2; ++b) counts[b] = 0.0;
+  for (int64_t i = 0; i < n; ++i) {
+    const double v = x[i * stride];
+    int32_t b;
+    if (v < lo) b = 0;
+    else if (!(v <= hi)) b = nbins + 1;
+    else { b = (int32_t)floor((v - lo) * scale); b = 1 + (b < nbins ? b : nbins - 1); }
+    counts[b] += 1.0;
+  }
+  return RSF_OK;
+}
+
 /* Pool collectives (include/rsf_abi.h): the checker is one process, so only world = 1 exists here —
  * enough to run the same host code against both libraries. */
 int rsf_comm_unique_id(uint8_t id[RSF_COMM_ID_BYTES]) {

@@ -59,6 +59,9 @@ def _worker(rank, port, out_dir):
         local = e.pool_summary(pool[:, rank * per:(rank + 1) * per].contiguous().numpy())
     glob = rdist.allreduce_summary(local)
     np.save(os.path.join(out_dir, f"summary_{rank}.npy"), np.array([glob[k] for k in ("n", "mean", "var", "min", "max")]))
+    with pkg.Engine(lib=lib) as e:  # ... and a fixed-bin histogram of the local shard, summed over ranks with one all-reduce
+        hist = rdist.allreduce_histogram(e.pool_histogram(pool[:, rank * per:(rank + 1) * per].contiguous().numpy(), 16, 900.0, 1100.0))
+    np.save(os.path.join(out_dir, f"hist_{rank}.npy"), hist.numpy())
     assert stats["iters_done"] == N_ITERS
     dist.barrier()
     dist.destroy_process_group()
@@ -88,5 +91,9 @@ def test_two_rank_pool_equals_single_process(pkg, oracle_lib, oracle_mod, tmp_pa
     x = pools[0].ravel()
     for r in range(WORLD):
         np.testing.assert_allclose(np.load(tmp_path / f"summary_{r}.npy"), [x.size, x.mean(), x.var(ddof=1), x.min(), x.max()], rtol=1e-12)
+    ref, _ = np.histogram(x, 16, (900.0, 1100.0))
+    for r in range(WORLD):
+        h = np.load(tmp_path / f"hist_{r}.npy")
+        np.testing.assert_array_equal(h, np.concatenate([[(x < 900.0).sum()], ref, [(x > 1100.0).sum()]]))
     assert pools[0].shape == (N_ITERS - NBURN + 1, C, 1)
     np.testing.assert_array_equal(pools[0], tq[NBURN - 1:])

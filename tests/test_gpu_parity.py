@@ -620,6 +620,26 @@ def test_pool_summary_and_kde(pkg, cpu_engine):
         assert abs(np.trapezoid(dens_h, grid) - 1.0) < 1e-3
 
 
+def test_pool_histogram(pkg, cpu_engine):
+    """Device fixed-bin histogram (LDS-privatised counting, integer atomics) vs the oracle: identical counts, host and device
+    buffers, every parameter of a trace block, many and few bins, edge values and NaN."""
+    import torch
+
+    rng = np.random.default_rng(6)
+    n = 1_000_003
+    trace = np.stack([rng.normal(1000.0, 40.0, n), rng.normal(0.011, 1e-3, n), rng.gamma(3.0, 2.0, n)], axis=1).reshape(-1, 1, 3)
+    trace[3, 0, 0], trace[4, 0, 0], trace[5, 0, 0], trace[6, 0, 0] = 900.0, 1100.0, np.nan, np.nextafter(1100.0, 0.0)
+    with pkg.Engine(mem="host") as eh, pkg.Engine(mem="device") as ed:
+        dev = torch.as_tensor(trace).cuda()
+        for p, (nbins, lo, hi) in enumerate(((40, 900.0, 1100.0), (1, 0.008, 0.014), (4096, 0.0, 30.0))):
+            ref = cpu_engine.pool_histogram(trace, nbins, lo, hi, param=p)
+            np.testing.assert_array_equal(eh.pool_histogram(trace, nbins, lo, hi, param=p), ref)
+            np.testing.assert_array_equal(ed.pool_histogram(dev, nbins, lo, hi, param=p).cpu().numpy(), ref)
+            assert ref.sum() == n
+        with pytest.raises(pkg.RsfError):
+            eh.pool_histogram(trace, 5000, 0.0, 1.0)
+
+
 def test_observation_groups(gpu_engine, cpu_engine, oracle_mod):
     """One observation series per chain group: GPU vs oracle, and the group blocks are used."""
     m = _models(oracle_mod, 500)

@@ -326,3 +326,22 @@ def test_dop853_chain_equals_reference_chain(cpu_engine, oracle_mod, golden, tag
     np.testing.assert_allclose(ts[:, 0], g["std2_after"], rtol=1e-10)
     np.testing.assert_allclose(np.where(g["inb"] == 1, g["ssq_new"], 0.0)[ta[:, 0] == 1],
                                g["ssq_after"][ta[:, 0] == 1], rtol=1e-10)
+
+
+def test_pool_histogram_is_numpy_histogram(cpu_engine, pkg):
+    """rsf_pool_histogram (the fixed-bin summary of SURVEY §8e): numpy.histogram semantics — equal bins over [lo, hi], the last one
+    closed at hi — plus the counts below / above the range (NaN counts as above); any parameter of a [n][d] trace block."""
+    rng = np.random.default_rng(2)
+    n = 50_007
+    trace = np.stack([rng.normal(1000.0, 40.0, n), rng.normal(0.011, 1e-3, n), rng.gamma(3.0, 2.0, n)], axis=1).reshape(-1, 1, 3)
+    trace[3, 0, 0], trace[4, 0, 0], trace[5, 0, 0], trace[6, 0, 0] = 900.0, 1100.0, np.nan, np.nextafter(1100.0, 0.0)   # the edges themselves
+    for p, (nbins, lo, hi) in enumerate(((40, 900.0, 1100.0), (7, 0.008, 0.014), (4096, 0.0, 30.0))):
+        x = trace[:, 0, p]
+        counts = cpu_engine.pool_histogram(trace, nbins, lo, hi, param=p)
+        ref, _ = np.histogram(x[np.isfinite(x)], nbins, (lo, hi))
+        assert counts.shape == (nbins + 2,) and counts.sum() == n
+        np.testing.assert_array_equal(counts[1:-1], ref)
+        assert counts[0] == (x < lo).sum() and counts[-1] == (x > hi).sum() + np.isnan(x).sum()
+    for bad in (dict(nbins=0, lo=0.0, hi=1.0), dict(nbins=4097, lo=0.0, hi=1.0), dict(nbins=8, lo=1.0, hi=1.0), dict(nbins=8, lo=0.0, hi=np.inf)):
+        with pytest.raises(pkg.RsfError):
+            cpu_engine.pool_histogram(trace, **bad)
