@@ -62,7 +62,8 @@ constexpr int kMaxBlock = 256;           // 4 waves: one per SIMD of a CU
 // (188 B of scratch per lane) two waves share a SIMD: 2.93e10 -> 3.90e10 at 262 144 chains, 2.89e10 -> 3.64e10 at
 // 131 072, -0.8 % at 65 536 chains, where there is only one wave per SIMD to begin with (profiles/r02/dop853_occupancy_ab.log).
 #ifndef RSF_D3_TRIP
-#define RSF_D3_TRIP 1  // three-parameter sampler: TIGHT loop trips of RSF_D3_TRIP * RSF_TIGHT_UNROLL steps (the one-parameter sampler: 2 *)
+#define RSF_D3_TRIP 2  // three-parameter sampler: TIGHT loop trips of RSF_D3_TRIP * RSF_TIGHT_UNROLL steps, like the one-parameter sampler's 2 *
+                       // (+2.3 % over 1 at 131 072 chains x nsteps 4000; costs 36-52 B of scratch per lane, all of it outside the loops)
 #endif
 #ifndef RSF_DP_MIN_BLOCKS
 #define RSF_DP_MIN_BLOCKS 2
@@ -307,18 +308,20 @@ __global__ void __launch_bounds__(kMaxBlock, MODE == DOP853 ? RSF_DP_MIN_BLOCKS 
   for (int p = 0; p < D; ++p) q[p] = 1.0;
 #pragma unroll
   for (int e = 0; e < D * D; ++e) V[e] = 0.0;
-  // adaptation window (shifted sums over the last adapt_interval samples): 3 + 3 + 9 doubles for D = 3 — thirty registers
-  // that would stay live across the forward solve, where the register budget is spent on the integrator (the compiler used
-  // to spill some of them: 56-124 B of scratch per lane).  For D = 3 the window therefore lives in its HBM arrays and is
-  // read-modified-written once per proposal (30 accesses against 4000 RK4 steps); D = 1 keeps its three values in registers.
+  // adaptation window (shifted sums over the last adapt_interval samples): 3 + 3 + 9 doubles for D = 3, and the proposal
+  // covariance V, 9 more — forty-eight registers that would stay live across the forward solve, where the register budget is
+  // spent on the integrator.  For D = 3 both therefore live in their HBM arrays: V is read where the proposal is formed, the
+  // window is read-modified-written once per proposal (~40 accesses against 4000 RK4 steps); D = 1 keeps its values in registers.
   constexpr bool kWinRegs = D == 1;
   double wr[D], ws[D], wq[D * D];
   int32_t wn = 0;
   if (valid) {
 #pragma unroll
     for (int p = 0; p < D; ++p) q[p] = A.q[i * D + p];
+    if (kWinRegs) {
 #pragma unroll
-    for (int e = 0; e < D * D; ++e) V[e] = A.V[i * D * D + e];
+      for (int e = 0; e < D * D; ++e) V[e] = A.V[i * D * D + e];
+    }
     ssq = A.ssq[i];
     std2 = A.std2[i];
   }
@@ -366,6 +369,10 @@ __global__ void __launch_bounds__(kMaxBlock, MODE == DOP853 ? RSF_DP_MIN_BLOCKS 
       }
     }
     double Lc[D * D], qn[D];
+    if (!kWinRegs && valid) {  // D = 3: the proposal covariance is read where it is used instead of living in 18 registers
+#pragma unroll
+      for (int e = 0; e < D * D; ++e) V[e] = A.V[i * D * D + e];
+    }
     rsf::chol_lower<D>(V, Lc);
     bool inb = valid;
 #pragma unroll
@@ -448,7 +455,10 @@ __global__ void __launch_bounds__(kMaxBlock, MODE == DOP853 ? RSF_DP_MIN_BLOCKS 
                 Vn[p * D + r] = 2.38 * 2.38 / (double)D * ((wq[p * D + r] - ws[p] * ws[r] / nn) / (nn - 1.0));
             if (rsf::chol_lower<D>(Vn, Ln)) {
 #pragma unroll
-              for (int e = 0; e < D * D; ++e) V[e] = Vn[e];
+              for (int e = 0; e < D * D; ++e) {
+                if (kWinRegs) V[e] = Vn[e];
+                else A.V[i * D * D + e] = Vn[e];
+              }
             }
           }
         }
@@ -465,8 +475,10 @@ __global__ void __launch_bounds__(kMaxBlock, MODE == DOP853 ? RSF_DP_MIN_BLOCKS 
   if (valid) {
 #pragma unroll
     for (int p = 0; p < D; ++p) A.q[i * D + p] = q[p];
+    if (kWinRegs) {
 #pragma unroll
-    for (int e = 0; e < D * D; ++e) A.V[i * D * D + e] = V[e];
+      for (int e = 0; e < D * D; ++e) A.V[i * D * D + e] = V[e];
+    }
     A.ssq[i] = ssq;
     A.std2[i] = std2;
     if (kWinRegs && A.adapt_mode != RSF_ADAPT_NONE) store_window();
