@@ -310,3 +310,13 @@ def test_posterior_figure_uses_the_engine_kde(pkg, model, monkeypatch):
     import matplotlib.pyplot as plt
 
     plt.close("all")
+
+
+def test_unknown_dc_is_reported_not_sampled(pkg, model, capsys):
+    """RSF.perform_sampling_and_plotting (RSF.py:874-878): a dc that is not in dc_list prints the reference's message and
+    returns without sampling."""
+    problem = pkg.RSF(number_slip_values=2, lowest_slip_value=500.0, largest_slip_value=1500.0, qstart=1000.0)
+    problem.model, problem.format = model, "json"
+    problem.perform_sampling_and_plotting(np.zeros(1000), 777.0, 10, None)
+    assert "Error: dc value 777.0 not found in dc_list." in capsys.readouterr().out
+    assert problem.posteriors == {}
