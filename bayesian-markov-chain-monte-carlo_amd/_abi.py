@@ -105,6 +105,9 @@ PROTOTYPES = {
     "rsf_comm_destroy": (c_int, [c_void_p]),
     "rsf_pool_allgather": (c_int, [c_void_p, _P, c_int64, _P]),
     "rsf_pool_allreduce_sum": (c_int, [c_void_p, _P, c_int64]),
+    "rsf_comm_init_all": (c_int, [POINTER(c_void_p), c_int32]),
+    "rsf_pool_allgather_all": (c_int, [POINTER(c_void_p), c_int32, POINTER(c_void_p), c_int64, POINTER(c_void_p)]),
+    "rsf_pool_allreduce_sum_all": (c_int, [POINTER(c_void_p), c_int32, POINTER(c_void_p), c_int64]),
     "rsf_philox4x32_10": (c_int, [POINTER(c_uint32), POINTER(c_uint32), POINTER(c_uint32)]),
     "rsf_mcmc_draws": (c_int, [c_uint64, c_int64, c_int64, c_int32, c_double, POINTER(c_double), POINTER(c_double), POINTER(c_double)]),
 }

@@ -76,13 +76,8 @@ __device__ __forceinline__ void set_tier(Lane &L);
 __device__ __forceinline__ Lane make_lane(double dc, double a, double b, const Consts &K) {
   Lane L;
   // reciprocals by rsf_math.h (<= 1 ulp from the IEEE quotient at a fifth of its instruction count)
-#ifdef RSF_MATH_OCML
-  const double inv_a = 1.0 / a;
-  L.inv_dc = 1.0 / dc;
-#else
   const double inv_a = fm::rcp(a);
   L.inv_dc = fm::rcp(dc);
-#endif
   L.kprime = (1e-2 * 10) * L.inv_dc;
   L.kia = L.kprime * inv_a;
   L.khh = L.kia * K.hh;
@@ -155,13 +150,8 @@ __device__ __forceinline__ void rhs_fast(double w, double x, double vl, double t
 
 // (w, 1/x) by full evaluation
 __device__ __forceinline__ void eval_full(double ms, double x, const Lane &L, const Consts &K, double &w, double &rx) {
-#ifdef RSF_MATH_OCML
-  w = ::exp(__builtin_fma(-L.boa, ::log(x), __builtin_fma(ms, L.kia, L.tc)));
-  rx = 1.0 / x;
-#else
   w = fm::exp(__builtin_fma(-L.boa, fm::log(x), __builtin_fma(ms, L.kia, L.tc)));
   rx = fm::rcp(x);
-#endif
 }
 
 // (w', 1/x') at (ms + dms, x1 = x + dx) from (w, rx) at (ms, x).  With rho = dx/x (= dtheta/theta) and
@@ -190,18 +180,10 @@ __device__ __forceinline__ double stage_t1(double vl, double rx_or_q, double br0
   return __builtin_fma(-L.beta, rx_or_q, vl);
 }
 
-
-#ifdef RSF_GUARD_F64
-struct Guard {
-  double rho, dlt;
-  double dlt_h;
-};
-#else
 struct Guard {
   float rho, dlt;
-  float dlt_h;  // TIGHT: |dlt| of the two half-step stages, held to 2^-10 so that their expm1 series is one term shorter
+  float dlt_h;  // TIGHT: |dlt| of the two half-step stages, held to 2^-10 (truncation of their expm1 series < 8e-18)
 };
-#endif
 
 __device__ __forceinline__ float hi_as_float(double x) { return __builtin_bit_cast(float, __double2hiint(x)); }
 constexpr float hi_pow2(int e) { return __builtin_bit_cast(float, (1023 + e) << 20); }  // high word of 2^e, as float
@@ -211,7 +193,7 @@ constexpr float hi_pow2(int e) { return __builtin_bit_cast(float, (1023 + e) << 
 template <int T>
 __device__ __forceinline__ void set_tier(Lane &L) {
   L.c_l1p = T == NARROW ? -1.0 / 6.0 : 1.0 / 7.0;  // (TIGHT needs none: 1 - rho/2 has inline constants only)
-  L.c_em1 = T == TIGHT ? 1.0 / 120.0 : 1.0 / 5040.0;
+  L.c_em1 = 1.0 / 5040.0;  // (TIGHT: 1/24 leads, c_em1h)
   L.c_em1h = 1.0 / 24.0;
   asm volatile("" : "+v"(L.c_l1p), "+v"(L.c_em1), "+v"(L.c_em1h));  // opaque: stays a register value, not re-materialised per step
 }
@@ -221,11 +203,7 @@ __device__ __forceinline__ void eval_incr(double kf, double dms_dt, double R, do
                                           double rx0, double &w, double &rx, Guard &g) {  // TIGHT && STAGE: rx returns q (stage_t1)
   // dk = kf * dms_dt (kf: kia times the step fraction);  rho = R * dth_dt (R: step fraction / Dc / x, once per step)
   const double rho = dth_dt * R;
-#ifdef RSF_GUARD_F64
-  g.rho = __builtin_fmax(g.rho, __builtin_fabs(rho));
-#else
   g.rho = __builtin_fmaxf(g.rho, __builtin_fabsf(hi_as_float(rho)));
-#endif
   double p;
   if (T == TIGHT) {
     p = __builtin_fma(rho, -0.5, 1.0);
@@ -244,31 +222,16 @@ __device__ __forceinline__ void eval_incr(double kf, double dms_dt, double R, do
   const double dlt = __builtin_fma(-(L.boa * rho), p, kf * dms_dt);  // d1 -> rho -> p -> dlt: three deep
   // TIGHT: expm1 to dlt^4/24 at every stage.  Half-step stages are held to |dlt| < 2^-10 (truncation dlt^5/120 < 7.4e-18 relative);
   // the full-step stage and the step's end point to |dlt| < 2^-9, where the same series truncates at < 2^-45/120 = 2.4e-16 —
-  // one ulp at the guard's edge, 8e-18 at the |dlt| ~ 1e-3 of Dc ~ 1000 — which saves their sixth-degree term
-  // (-DRSF_TIGHT_LONG_FULL keeps it: the v20 arithmetic, for A/B measurement).
-#ifdef RSF_TIGHT_LONG_FULL
-  constexpr bool kShortSeries = T == TIGHT && HALF;
-#else
-  constexpr bool kShortSeries = T == TIGHT;
-#endif
+  // one ulp at the guard's edge, 8e-18 at the |dlt| ~ 1e-3 of Dc ~ 1000 — which saves their sixth-degree term.
   constexpr bool kShort = T == TIGHT && HALF;  // guard accumulator of the half-step stages (2^-10)
-#ifdef RSF_GUARD_F64
-  if (kShort) g.dlt_h = __builtin_fmax(g.dlt_h, __builtin_fabs(dlt));
-  else g.dlt = __builtin_fmax(g.dlt, __builtin_fabs(dlt));
-#else
   if (kShort) g.dlt_h = __builtin_fmaxf(g.dlt_h, __builtin_fabsf(hi_as_float(dlt)));
   else g.dlt = __builtin_fmaxf(g.dlt, __builtin_fabsf(hi_as_float(dlt)));
-#endif
   double e;
-  if (kShortSeries) {
+  if (T == TIGHT) {
     e = L.c_em1h;
   } else {
-    if (T == TIGHT) {
-      e = L.c_em1;
-    } else {
-      e = fm::hfma(L.c_em1, dlt, 1.0 / 720.0);
-      e = fm::hfma(e, dlt, 1.0 / 120.0);
-    }
+    e = fm::hfma(L.c_em1, dlt, 1.0 / 720.0);
+    e = fm::hfma(e, dlt, 1.0 / 120.0);
     e = fm::hfma(e, dlt, 1.0 / 24.0);
   }
   e = fm::hfma(e, dlt, 1.0 / 6.0);
@@ -290,13 +253,8 @@ __device__ __forceinline__ void eval_incr(double kf, double dms_dt, double R, do
 
 template <int T>
 __device__ __forceinline__ bool guard_ok(const Guard &g) {  // NaN passes through (see Guard)
-#ifdef RSF_GUARD_F64
-  return (g.rho < (T == WIDE ? 0x1.0p-7 : (T == NARROW ? 0x1.0p-9 : 0x1.0p-20))) && (g.dlt < (T == TIGHT ? 0x1.0p-9 : 0x1.0p-6)) &&
-         (T != TIGHT || g.dlt_h < 0x1.0p-10);
-#else
   return (g.rho < (T == WIDE ? hi_pow2(-7) : (T == NARROW ? hi_pow2(-9) : hi_pow2(-20)))) &&
          (g.dlt < (T == TIGHT ? hi_pow2(-9) : hi_pow2(-6))) && (T != TIGHT || g.dlt_h < hi_pow2(-10));
-#endif
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -308,12 +266,10 @@ __device__ __forceinline__ bool guard_ok(const Guard &g) {  // NaN passes throug
 // instruction, nop and branch costs a full ~5-cycle issue slot (tools/microbench_fp64.hip).
 // The largest increments of a PAIR of steps are checked once (integrate_pairs); if a lane left the tier's
 // guard region (stiff small-Dc proposals) the pair is redone from the saved start point with full
-// evaluations (rk4_cold).  Every RSF_RESYNC steps (w, 1/x) are recomputed in full so rounding in the
+// evaluations (rk4_cold).  Every kResync steps (w, 1/x) are recomputed in full so rounding in the
 // incremental products cannot accumulate.
 // ---------------------------------------------------------------------------------------------
-#ifndef RSF_RESYNC
-#define RSF_RESYNC 128
-#endif
+constexpr int kResync = 128;  // power of two; every trip length below divides it
 
 // Both step functions return the weighted sum of the V derivatives, k1 + 2 k2 + 2 k3 + k4, IN UNITS OF vk (rhs_tail /
 // rhs_fast): the velocity increment of the step is (h/6) vk = L.h6v times it.  V itself never feeds back into the RHS, so the hot loop does not carry it: with one
@@ -371,27 +327,6 @@ __device__ __forceinline__ double rk4_fast(State &s, double vl0, double vlm, dou
   s.w = w;
   s.rx = rx;
   return __builtin_fma(2.0, sm, sv);
-}
-
-// advance one step; `resync` (wave-uniform, from the step index) asks for a full re-evaluation of (w, 1/th) first
-template <bool DAMP>
-__device__ __forceinline__ void rk4_step(State &s, bool resync, double vl0, double vlm, double vl1, const Lane &L,
-                                         const Consts &K) {
-#ifdef RSF_NO_INCREMENTAL
-  s.V = __builtin_fma(L.h6v, rk4_cold<DAMP>(s, vl0, vlm, vl1, L, K), s.V);
-  (void)resync;
-#else
-  if (resync) eval_full(s.ms, s.x, L, K, s.w, s.rx);
-  const State save = s;
-  Guard g = {0, 0, 0};
-  double dv = rk4_fast<DAMP, WIDE>(s, vl0, vlm, vl1, L, K, g);
-  if (__builtin_expect(!guard_ok<WIDE>(g), 0)) {  // an increment too large (or Inf; NaN passes through): cold path
-    s = save;
-    dv = rk4_cold<DAMP>(s, vl0, vlm, vl1, L, K);
-    eval_full(s.ms, s.x, L, K, s.w, s.rx);
-  }
-  s.V = __builtin_fma(L.h6v, dv, save.V);
-#endif
 }
 
 __device__ __forceinline__ State initial_state(double dc, const Lane &L, const Consts &K) {
@@ -466,6 +401,25 @@ __device__ __forceinline__ void emit_sample(double vnow, Emit &em, double obs, c
   ++em.ko;
 }
 
+// One trip: NU straight-line steps of tier T from s (L already carries the tier's coefficients, set_tier);
+// dv[j] = the weighted V-derivative sum of step j.  Returns whether this lane left the tier's guard region — its
+// values are then not to be used: the caller restores the state it saved and takes trip_cold.
+template <bool DAMP, int T, int NU>
+__device__ __forceinline__ bool trip_fast(const double *v, const Lane &L, const Consts &K, State &s, double (&dv)[NU]) {
+  Guard g = {0, 0, 0};
+#pragma unroll
+  for (int j = 0; j < NU; ++j) dv[j] = rk4_fast<DAMP, T>(s, v[2 * j], v[2 * j + 1], v[2 * j + 2], L, K, g);
+  return !guard_ok<T>(g);
+}
+
+// the same trip with a full evaluation at every stage (exact whatever the increments), (w, 1/x) re-formed at its end
+template <bool DAMP, int NU>
+__device__ __forceinline__ void trip_cold(const double *v, const Lane &L, const Consts &K, State &s, double (&dv)[NU]) {
+#pragma unroll 1
+  for (int j = 0; j < NU; ++j) dv[j] = rk4_cold<DAMP>(s, v[2 * j], v[2 * j + 1], v[2 * j + 2], L, K);
+  eval_full(s.ms, s.x, L, K, s.w, s.rx);
+}
+
 // integrates RK4 steps [r, nsteps) of the chunk two at a time; returns the first step not yet integrated
 template <bool DAMP, bool WANT_SSQ, bool WANT_ACC, int T, bool S1>
 __device__ __forceinline__ int integrate_pairs(const double *lds, const double *ld, const Consts &K, Lane L, int k0, int r,
@@ -475,27 +429,23 @@ __device__ __forceinline__ int integrate_pairs(const double *lds, const double *
     const double *v = lds + 2 * r;
     // observations this pair can complete, read before the arithmetic (S > 1: at most one sample per pair)
     const double obs0 = WANT_SSQ ? ld[S1 ? r : em.ko] : 0.0, obs1 = (WANT_SSQ && S1) ? ld[r + 1] : 0.0;
-    if ((r & (RSF_RESYNC - 1)) == 0) eval_full(s.ms, s.x, L, K, s.w, s.rx);
+    if ((r & (kResync - 1)) == 0) eval_full(s.ms, s.x, L, K, s.w, s.rx);
     const State save = s;
-    Guard g = {0, 0, 0};
-    double dv0 = rk4_fast<DAMP, T>(s, v[0], v[1], v[2], L, K, g);
-    double dv1 = rk4_fast<DAMP, T>(s, v[2], v[3], v[4], L, K, g);
-    const bool bad = !guard_ok<T>(g);
+    double dv[2];
+    const bool bad = trip_fast<DAMP, T, 2>(v, L, K, s, dv);
     const unsigned long long badmask = __builtin_amdgcn_ballot_w64(bad);  // wave-uniform, straight from the compares
     if (__builtin_expect(badmask != 0, 0)) {  // scalar branch: the hot path carries no exec-mask bookkeeping
       if (bad) {
         s = save;
-        dv0 = rk4_cold<DAMP>(s, v[0], v[1], v[2], L, K);
-        dv1 = rk4_cold<DAMP>(s, v[2], v[3], v[4], L, K);
-        eval_full(s.ms, s.x, L, K, s.w, s.rx);
+        trip_cold<DAMP, 2>(v, L, K, s, dv);
       }
     }
     if (S1) {  // sample index == step index: no bookkeeping, and V is not carried at all
-      emit_incr<WANT_SSQ, WANT_ACC>(dv0, r, obs0, L, k0, ssq, acc_out, stride);
-      emit_incr<WANT_SSQ, WANT_ACC>(dv1, r + 1, obs1, L, k0, ssq, acc_out, stride);
+      emit_incr<WANT_SSQ, WANT_ACC>(dv[0], r, obs0, L, k0, ssq, acc_out, stride);
+      emit_incr<WANT_SSQ, WANT_ACC>(dv[1], r + 1, obs1, L, k0, ssq, acc_out, stride);
     } else {
-      const double vmid = __builtin_fma(L.h6v, dv0, save.V);
-      s.V = __builtin_fma(L.h6v, dv1, vmid);
+      const double vmid = __builtin_fma(L.h6v, dv[0], save.V);
+      s.V = __builtin_fma(L.h6v, dv[1], vmid);
       if (++em.phase == K.S) { em.phase = 0; emit_sample<WANT_SSQ, WANT_ACC>(vmid, em, obs0, K, k0, ssq, acc_out, stride); }
       if (++em.phase == K.S) { em.phase = 0; emit_sample<WANT_SSQ, WANT_ACC>(s.V, em, obs0, K, k0, ssq, acc_out, stride); }
     }
@@ -509,17 +459,13 @@ __device__ __forceinline__ int integrate_pairs(const double *lds, const double *
 // of that compare-and-branch, ~150 cycles, whatever the trip holds (2 -> 4 -> 8 steps per trip: +12 %, +14 % at cfg1).
 // A tripped guard redoes the trip with full evaluations; TIGHT and NARROW then hand the rest of the chunk to the next
 // wider tier (`tripped`), like integrate_pairs, which takes whatever remainder (< NU steps) is left.
-#ifndef RSF_TIGHT_UNROLL
-#define RSF_TIGHT_UNROLL 8
-#endif
-#ifndef RSF_WIDER_UNROLL
-#define RSF_WIDER_UNROLL 4
-#endif
+constexpr int kTightUnroll = 8;  // steps per trip of the TIGHT loop (the one-parameter sampler runs 2 * kTightUnroll, rsf_kernels.h)
+constexpr int kWiderUnroll = 4;  // NARROW and WIDE
 template <bool DAMP, bool WANT_SSQ, bool WANT_ACC, int T, bool S1, int NU>
 __device__ __forceinline__ int integrate_multi(const double *lds, const double *ld, const Consts &K, Lane L, int k0, int kn, int r,
                                                int nsteps, State &s, Emit &em, double &ssq, double *acc_out, int64_t stride,
                                                bool &tripped) {
-  static_assert(NU >= 2 && (RSF_RESYNC % NU) == 0, "the resync test looks at the first step of a trip");
+  static_assert(NU >= 2 && (kResync % NU) == 0, "the resync test looks at the first step of a trip");
   set_tier<T>(L);
   for (; r + NU <= nsteps; r += NU) {
     const double *v = lds + 2 * r;
@@ -529,19 +475,14 @@ __device__ __forceinline__ int integrate_multi(const double *lds, const double *
     double obs[NO], dv[NU];
 #pragma unroll
     for (int j = 0; j < NO; ++j) obs[j] = WANT_SSQ ? ld[S1 ? r + j : min(em.ko + j, kn - 1)] : 0.0;
-    if ((r & (RSF_RESYNC - 1)) == 0) eval_full(s.ms, s.x, L, K, s.w, s.rx);
+    if ((r & (kResync - 1)) == 0) eval_full(s.ms, s.x, L, K, s.w, s.rx);
     const State save = s;
-    Guard g = {0, 0, 0};
-#pragma unroll
-    for (int j = 0; j < NU; ++j) dv[j] = rk4_fast<DAMP, T>(s, v[2 * j], v[2 * j + 1], v[2 * j + 2], L, K, g);
-    const bool bad = !guard_ok<T>(g);
+    const bool bad = trip_fast<DAMP, T, NU>(v, L, K, s, dv);
     const unsigned long long badmask = __builtin_amdgcn_ballot_w64(bad);  // wave-uniform, straight from the compares
     if (__builtin_expect(badmask != 0, 0)) {  // scalar branch: the hot path carries no exec-mask bookkeeping
       if (bad) {
         s = save;
-#pragma unroll 1
-        for (int j = 0; j < NU; ++j) dv[j] = rk4_cold<DAMP>(s, v[2 * j], v[2 * j + 1], v[2 * j + 2], L, K);
-        eval_full(s.ms, s.x, L, K, s.w, s.rx);
+        trip_cold<DAMP, NU>(v, L, K, s, dv);
       }
     }
     if (S1) {
@@ -568,18 +509,18 @@ __device__ __forceinline__ int integrate_multi(const double *lds, const double *
   return r;
 }
 
+// Wave-uniform choice of the starting tier — a speed decision only: every tier is exact to rounding inside its guard, and
+// a tier whose guard trips redoes that trip in full and hands over to the next wider one.  TIGHT is tried whenever the
+// mu increment allows it (|V_l - v| <~ 1.2 V_ref): theta tracks its steady state closely (|dtheta/theta| ~ 1e-7 per
+// stage at Dc ~ 1000, h = 0.1), which no a-priori bound captures.
+__device__ __forceinline__ int start_tier(const Lane &L, const Consts &K) {
+  return !__any(!(1.2 * K.V_ref * K.h * L.kia < 0x1.0p-9)) ? TIGHT : (!__any(!(4.0 * K.h * L.vdc < 0x1.0p-9)) ? NARROW : WIDE);
+}
+
 template <bool DAMP, bool WANT_SSQ, bool WANT_ACC, bool S1, int NUT>
 __device__ __forceinline__ void integrate_tiers(const double *lds, const double *ld, const Consts &K, const Lane &L, int k0,
                                                 int kn, State &s, double &ssq, double *acc_out, int64_t stride) {
-  // Wave-uniform choice of the starting tier — a speed decision only: every tier is exact to rounding inside
-  // its guard, and a tier whose guard trips redoes that pair in full and hands over to the next wider one.
-  // TIGHT is tried whenever the mu increment allows it (|V_l - v| <~ 1.2 V_ref): theta tracks its steady state
-  // closely (|dtheta/theta| ~ 1e-7 per stage at Dc ~ 1000, h = 0.1), which no a-priori bound captures.
-#ifdef RSF_FORCE_NARROW
-  const int tier = NARROW;
-#else
-  const int tier = !__any(!(1.2 * K.V_ref * K.h * L.kia < 0x1.0p-9)) ? TIGHT : (!__any(!(4.0 * K.h * L.vdc < 0x1.0p-9)) ? NARROW : WIDE);
-#endif
+  const int tier = start_tier(L, K);
   const int nsteps = S1 ? kn : K.S * kn;
   Emit em = {0, 0, s.V};
   int r = 0;
@@ -587,20 +528,14 @@ __device__ __forceinline__ void integrate_tiers(const double *lds, const double 
   // `t_trip` / `n_trip`: that tier's guard tripped in the long-trip loop, the rest goes to the next wider tier
   bool t_trip = false, n_trip = false, unused = false;
   if (tier == TIGHT) {
-#ifndef RSF_NO_MULTI
     r = integrate_multi<DAMP, WANT_SSQ, WANT_ACC, TIGHT, S1, NUT>(lds, ld, K, L, k0, kn, r, nsteps, s, em, ssq, acc_out, stride, t_trip);
-#endif
     if (!t_trip) r = integrate_pairs<DAMP, WANT_SSQ, WANT_ACC, TIGHT, S1>(lds, ld, K, L, k0, r, nsteps, s, em, ssq, acc_out, stride);
   }
   if (tier <= NARROW) {
-#ifndef RSF_NO_MULTI
-    r = integrate_multi<DAMP, WANT_SSQ, WANT_ACC, NARROW, S1, RSF_WIDER_UNROLL>(lds, ld, K, L, k0, kn, r, nsteps, s, em, ssq, acc_out, stride, n_trip);
-#endif
+    r = integrate_multi<DAMP, WANT_SSQ, WANT_ACC, NARROW, S1, kWiderUnroll>(lds, ld, K, L, k0, kn, r, nsteps, s, em, ssq, acc_out, stride, n_trip);
     if (!n_trip) r = integrate_pairs<DAMP, WANT_SSQ, WANT_ACC, NARROW, S1>(lds, ld, K, L, k0, r, nsteps, s, em, ssq, acc_out, stride);
   }
-#ifndef RSF_NO_MULTI
-  r = integrate_multi<DAMP, WANT_SSQ, WANT_ACC, WIDE, S1, RSF_WIDER_UNROLL>(lds, ld, K, L, k0, kn, r, nsteps, s, em, ssq, acc_out, stride, unused);
-#endif
+  r = integrate_multi<DAMP, WANT_SSQ, WANT_ACC, WIDE, S1, kWiderUnroll>(lds, ld, K, L, k0, kn, r, nsteps, s, em, ssq, acc_out, stride, unused);
   r = integrate_pairs<DAMP, WANT_SSQ, WANT_ACC, WIDE, S1>(lds, ld, K, L, k0, r, nsteps, s, em, ssq, acc_out, stride);
   if (r < nsteps) {  // odd last step of the chunk (it always completes a sample): one WIDE step, cold if its guard trips
     const double *v = lds + 2 * r;
@@ -608,17 +543,15 @@ __device__ __forceinline__ void integrate_tiers(const double *lds, const double 
     Lane Lw = L;
     set_tier<WIDE>(Lw);
     const State save = s;
-    Guard g = {0, 0, 0};
-    double dv = rk4_fast<DAMP, WIDE>(s, v[0], v[1], v[2], Lw, K, g);
-    if (__builtin_expect(!guard_ok<WIDE>(g), 0)) {
+    double dv[1];
+    if (__builtin_expect(trip_fast<DAMP, WIDE, 1>(v, Lw, K, s, dv), 0)) {
       s = save;
-      dv = rk4_cold<DAMP>(s, v[0], v[1], v[2], L, K);
-      eval_full(s.ms, s.x, L, K, s.w, s.rx);
+      trip_cold<DAMP, 1>(v, L, K, s, dv);
     }
     if (S1) {
-      emit_incr<WANT_SSQ, WANT_ACC>(dv, kn - 1, obs, L, k0, ssq, acc_out, stride);
+      emit_incr<WANT_SSQ, WANT_ACC>(dv[0], kn - 1, obs, L, k0, ssq, acc_out, stride);
     } else {
-      s.V = __builtin_fma(L.h6v, dv, s.V);
+      s.V = __builtin_fma(L.h6v, dv[0], s.V);
       emit_at<WANT_SSQ, WANT_ACC>(s.V, em.vprev, kn - 1, obs, K, k0, ssq, acc_out, stride);
     }
   }
@@ -630,37 +563,15 @@ template <bool DAMP, bool WANT_SSQ, bool WANT_ACC, int NUT>
 __device__ __forceinline__ void integrate_chunk(const double *lds, const Consts &K, const Lane &L, int k0,
                                                 int kn, State &s, double &ssq, double *acc_out, int64_t stride) {
   const double *ld = lds + lds_data_offset(K);
-#ifndef RSF_NO_INCREMENTAL
-  if (K.S == 1) {
-    integrate_tiers<DAMP, WANT_SSQ, WANT_ACC, true, NUT>(lds, ld, K, L, k0, kn, s, ssq, acc_out, stride);
-    return;
-  }
-#ifndef RSF_S1_ONLY
-  integrate_tiers<DAMP, WANT_SSQ, WANT_ACC, false, NUT>(lds, ld, K, L, k0, kn, s, ssq, acc_out, stride);
-  return;
-#endif
-#endif
-#if defined(RSF_NO_INCREMENTAL) || defined(RSF_S1_ONLY)
-  int j = 0;
-  for (int kk = 0; kk < kn; ++kk) {
-    const double vprev = s.V;
-    for (int sub = 0; sub < K.S; ++sub, j += 2)
-      rk4_step<DAMP>(s, (j & (2 * RSF_RESYNC - 1)) == 2 * RSF_RESYNC - 2, lds[j], lds[j + 1], lds[j + 2], L, K);
-    const double ak = (s.V - vprev) * K.inv_dt;  // RateStateModel.py:388
-    if (WANT_ACC) acc_out[(int64_t)(k0 + kk) * stride] = ak;
-    if (WANT_SSQ) {
-      const double r = ak - ld[kk];
-      ssq += r * r;
-    }
-  }
-#endif
+  if (K.S == 1) integrate_tiers<DAMP, WANT_SSQ, WANT_ACC, true, NUT>(lds, ld, K, L, k0, kn, s, ssq, acc_out, stride);
+  else integrate_tiers<DAMP, WANT_SSQ, WANT_ACC, false, NUT>(lds, ld, K, L, k0, kn, s, ssq, acc_out, stride);
 }
 
 // Full forward solve for one lane.  Every thread of the workgroup must call it (chunk staging has barriers);
 // `resident` (workgroup-uniform): the single chunk is already staged, nothing is re-staged.
 // NUT: RK4 steps per trip of the TIGHT loop (integrate_multi); 16 where the kernel's registers allow it (one-parameter
 // sampler), 8 otherwise
-template <bool DAMP, bool WANT_SSQ, bool WANT_ACC, int NUT = RSF_TIGHT_UNROLL>
+template <bool DAMP, bool WANT_SSQ, bool WANT_ACC, int NUT = kTightUnroll>
 __device__ __forceinline__ double solve(double *lds, const Consts &K, bool resident, bool active, double dc, double a,
                                         double b, double *acc_out, int64_t stride) {
   const Lane L = make_lane(dc, a, b, K);
@@ -715,26 +626,14 @@ __device__ __forceinline__ double u53(uint32_t hi, uint32_t lo) {
 // bits, which matters only when an accept test sits within ~1e-15 of its threshold (tests: draws to 1e-12).
 __device__ __forceinline__ void normal_pair(const uint32_t w[4], double &z0, double &z1) {
   const double u1 = u53(w[0], w[1]), u2 = u53(w[2], w[3]);
-#ifdef RSF_MATH_OCML
-  const double r = sqrt(-2.0 * ::log(u1));
-  double s, c;
-  sincos(6.283185307179586476925286766559 * u2, &s, &c);
-#else
   const double r = sqrt(-2.0 * fm::log(u1));
   double s, c;
   fm::sincos2pi(u2, s, c);
-#endif
   z0 = r * c;
   z1 = r * s;
 }
 
-__device__ __forceinline__ double rng_log(double x) {
-#ifdef RSF_MATH_OCML
-  return ::log(x);
-#else
-  return fm::log(x);
-#endif
-}
+__device__ __forceinline__ double rng_log(double x) { return fm::log(x); }
 
 // Marsaglia & Tsang (2000), shape >= 1, log acceptance test only.  d = shape - 1/3 and c = 1/sqrt(9 d) come from
 // the host (chain-independent).

@@ -1,15 +1,5 @@
-// rsf_hip.hip — gfx950 (MI355X / CDNA4) implementation of include/rsf_abi.h.
-//
-// Kernels (one lane = one chain, wave64 = 64 independent chains, fp64 VALU bound; no MFMA —
-// the path is an elementwise ODE recurrence plus per-lane reductions, not a contraction):
-//   forward_kernel  K1  batched RateStateModel.evaluate + SSq        (RateStateModel.py:188-395, MCMC.py:381-387)
-//   init_kernel     K4  compute_initial_covariance + initial SSq     (MCMC.py:244-266, 468)
-//   mcmc_kernel     K2  n_iters fused Metropolis iterations          (MCMC.py:494-527)
-//   probe_kernel    K3  Philox / variate self-test entry points
-// The chain-independent tables (loading velocity V_l at the RK4 stage times, observation) are
-// staged through LDS once per workgroup (or per chunk when they exceed the LDS budget) and
-// read as wave-wide broadcasts; per-chain state lives in registers for the whole launch and
-// touches HBM only at launch start/end plus one coalesced trace row per iteration.
+// rsf_hip.hip — gfx950 (MI355X / CDNA4) implementation of include/rsf_abi.h: the host side of the C ABI.
+// The kernels are in rsf_kernels.h (device building blocks: rsf_device*.h, rsf_math.h).
 //
 // There is no host fallback in this file: every entry point either runs on the GPU or fails.
 #include <hip/hip_runtime.h>
@@ -27,11 +17,10 @@
 #include <vector>
 
 #include "../../include/rsf_abi.h"
-#include "rsf_device.h"
-#include "rsf_device_dop853.h"
-#include "rsf_device_f32.h"
+#include "rsf_kernels.h"
 
 using rsf::Consts;
+using namespace rsfk;
 
 namespace {
 
@@ -50,573 +39,6 @@ int fail(int code, const char *fmt, ...) {
     hipError_t e_ = (expr);                                                                   \
     if (e_ != hipSuccess) return fail(RSF_ERR_DEVICE, "%s -> %s", #expr, hipGetErrorString(e_)); \
   } while (0)
-
-enum Mode : int { RK4_F64 = 0, RK4_F32 = 1, DOP853 = 2 };  // how the ODE is integrated (rsf_model.flags)
-
-constexpr int kMaxBlock = 256;           // 4 waves: one per SIMD of a CU
-// Register budget of the RK4 sampler kernel: at least this many workgroups per CU, i.e. waves per SIMD (2 => at most
-// 256 of the 512 unified registers per lane).  cfg2 runs 4 waves per SIMD worth of chains, so a kernel that drifts
-// above 256 registers would run it in four rounds instead of two.  The DOP853 sampler (12 stage vectors) is held to the
-// same budget: unbounded it took 300 registers (256 + 44 AGPRs) and ran ONE wave per SIMD whatever the chain count, its
-// fp64 pipe 61 % busy behind 248 scalar instructions per interval (profiles/r02/cfg1_dop853_v19_pmc.json); at 256 registers
-// (188 B of scratch per lane) two waves share a SIMD: 2.93e10 -> 3.90e10 at 262 144 chains, 2.89e10 -> 3.64e10 at
-// 131 072, -0.8 % at 65 536 chains, where there is only one wave per SIMD to begin with (profiles/r02/dop853_occupancy_ab.log).
-#ifndef RSF_D3_TRIP
-#define RSF_D3_TRIP 2  // three-parameter sampler: TIGHT loop trips of RSF_D3_TRIP * RSF_TIGHT_UNROLL steps, like the one-parameter sampler's 2 *
-                       // (+2.3 % over 1 at 131 072 chains x nsteps 4000; costs 36-52 B of scratch per lane, all of it outside the loops)
-#endif
-#ifndef RSF_DP_MIN_BLOCKS
-#define RSF_DP_MIN_BLOCKS 2
-#endif
-#ifndef RSF_MIN_BLOCKS
-#define RSF_MIN_BLOCKS 2
-#endif
-// LDS per workgroup for the loading table + observation chunk.  The sampler kernel's register budget admits two
-// workgroups per CU (RSF_MIN_BLOCKS), so 64 KiB each fits the CU's 160 KiB; nsteps 2000 (48 KB) then stays resident for
-// the whole launch instead of being staged twice per proposal (+1.3 % at cfg2).
-#ifndef RSF_LDS_BUDGET_KB
-#define RSF_LDS_BUDGET_KB 64
-#endif
-constexpr size_t kLdsBudget = RSF_LDS_BUDGET_KB * 1024;
-
-// ---------------------------------------------------------------------------------------------
-// kernels
-// ---------------------------------------------------------------------------------------------
-template <bool DAMP, bool WANT_SSQ, bool WANT_ACC, int MODE>
-__global__ void __launch_bounds__(kMaxBlock)
-forward_kernel(Consts K, int64_t n, const double *__restrict__ dc, const double *__restrict__ a,
-               const double *__restrict__ b, double *__restrict__ ssq_out, double *__restrict__ acc_out) {
-  extern __shared__ __attribute__((aligned(16))) double lds[];
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const bool active = i < n;
-  const double dci = active ? dc[i] : 1.0;
-  const double ai = (active && a) ? a[i] : K.a_def;
-  const double bi = (active && b) ? b[i] : K.b_def;
-  double *acc_i = WANT_ACC ? acc_out + i : nullptr;
-  const bool resident = K.nchunks == 1;
-  double ssq;
-  if constexpr (MODE == RK4_F32) {
-    float *lds32 = reinterpret_cast<float *>(lds);
-    if (resident) rsf::f32::stage_chunk32(lds32, K, 1, K.nout - 1);
-    ssq = rsf::f32::solve32<DAMP, WANT_SSQ, WANT_ACC>(lds32, K, resident, active, dci, ai, bi, acc_i, n);
-  } else {
-    if constexpr (MODE == DOP853) {
-      if (resident) rsf::dp::stage_chunk_dp(lds, K, 1, K.nout - 1);
-      ssq = rsf::dp::solve<DAMP, WANT_SSQ, WANT_ACC>(lds, K, resident, active, dci, ai, bi, acc_i, n);
-    } else {
-      if (resident) rsf::stage_chunk(lds, K, 1, K.nout - 1);
-      ssq = rsf::solve<DAMP, WANT_SSQ, WANT_ACC, 2 * RSF_TIGHT_UNROLL>(lds, K, resident, active, dci, ai, bi, acc_i, n);
-    }
-  }
-  if (WANT_SSQ && active) ssq_out[i] = ssq;
-}
-
-struct InitArgs {
-  int64_t C;
-  double fd;       // forward-difference relative step, MCMC.py:251
-  double inv_dof;  // 1 / (nout - len(qpriors)), MCMC.py:261
-  const double *q0;
-  double *ssq, *std2, *V;
-};
-
-// Per chain: the unperturbed solve and one perturbed solve per parameter advance in lockstep in
-// one lane, so the sensitivity products X^T X accumulate without storing trajectories.
-template <int D, bool DAMP>
-__global__ void __launch_bounds__(kMaxBlock) init_kernel(Consts K, InitArgs A) {
-  extern __shared__ __attribute__((aligned(16))) double lds[];
-  rsf::select_group(K);
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const bool active = i < A.C;
-  double p0[3] = {1.0, K.a_def, K.b_def};
-  if (active) {
-    p0[0] = A.q0[i * D];
-    if (D == 3) { p0[1] = A.q0[i * D + 1]; p0[2] = A.q0[i * D + 2]; }
-  }
-  rsf::Lane L[D + 1];
-  rsf::State st[D + 1];
-  double inv_den[D];
-  L[0] = rsf::make_lane(p0[0], p0[1], p0[2], K);
-  st[0] = rsf::initial_state(p0[0], L[0], K);
-#pragma unroll
-  for (int p = 0; p < D; ++p) {
-    double pq[3] = {p0[0], p0[1], p0[2]};
-    pq[p] = pq[p] * (1 + A.fd);
-    inv_den[p] = 1.0 / (pq[p] * A.fd);  // perturbed value in the denominator, MCMC.py:264
-    L[p + 1] = rsf::make_lane(pq[0], pq[1], pq[2], K);
-    st[p + 1] = rsf::initial_state(pq[0], L[p + 1], K);
-  }
-  double xtx[D * D];
-#pragma unroll
-  for (int e = 0; e < D * D; ++e) xtx[e] = 0.0;
-  double ssq = 0.0;
-  if (active) { const double d0 = K.data[0]; ssq = d0 * d0; }
-  const double *ld = lds + rsf::lds_data_offset(K);
-  for (int k0 = 1; k0 < K.nout; k0 += K.kc) {
-    const int kn = min(K.kc, K.nout - k0);
-    rsf::stage_chunk(lds, K, k0, kn);
-    if (!active) continue;
-    int j = 0;
-    for (int kk = 0; kk < kn; ++kk) {
-      double ak[D + 1];
-#pragma unroll
-      for (int t = 0; t <= D; ++t) ak[t] = st[t].V;
-      for (int s = 0; s < K.S; ++s, j += 2) {
-#pragma unroll
-        for (int t = 0; t <= D; ++t)
-          rsf::rk4_step<DAMP>(st[t], (j & (2 * RSF_RESYNC - 1)) == 2 * RSF_RESYNC - 2, lds[j], lds[j + 1], lds[j + 2], L[t], K);
-      }
-#pragma unroll
-      for (int t = 0; t <= D; ++t) ak[t] = (st[t].V - ak[t]) * K.inv_dt;
-      const double r = ak[0] - ld[kk];
-      ssq += r * r;
-      double x[D];
-#pragma unroll
-      for (int p = 0; p < D; ++p) x[p] = (ak[p + 1] - ak[0]) * inv_den[p];
-#pragma unroll
-      for (int p = 0; p < D; ++p)
-#pragma unroll
-        for (int r2 = 0; r2 < D; ++r2) xtx[p * D + r2] += x[p] * x[r2];
-    }
-  }
-  if (active) {
-    const double std2 = ssq * A.inv_dof;
-    double xi[D * D];
-    rsf::sym_inverse<D>(xtx, xi);
-#pragma unroll
-    for (int e = 0; e < D * D; ++e) A.V[i * D * D + e] = std2 * xi[e];  // MCMC.py:266
-    A.std2[i] = std2;
-    A.ssq[i] = ssq;
-  }
-}
-
-// compute_initial_covariance + initial SSq in the reference's DOP853 scheme: the unperturbed and the perturbed
-// trajectories take their dop853 calls interval by interval in one lane (each with its own carried step size).
-template <int D, bool DAMP>
-__global__ void __launch_bounds__(kMaxBlock) init_dp_kernel(Consts K, InitArgs A) {
-  extern __shared__ __attribute__((aligned(16))) double lds[];
-  rsf::select_group(K);
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const bool active = i < A.C;
-  double p0[3] = {1.0, K.a_def, K.b_def};
-  if (active) {
-    p0[0] = A.q0[i * D];
-    if (D == 3) { p0[1] = A.q0[i * D + 1]; p0[2] = A.q0[i * D + 2]; }
-  }
-  rsf::dp::LaneD L[D + 1];
-  double y[D + 1][3], x[D + 1], hc[D + 1], vprev[D + 1], inv_den[D];
-  bool failed[D + 1], have_kf[D + 1];
-  double kfs[D + 1][3];
-  rsf::dp::Base bfs[D + 1];
-#pragma unroll
-  for (int t = 0; t <= D; ++t) {
-    double pq[3] = {p0[0], p0[1], p0[2]};
-    if (t > 0) {
-      pq[t - 1] = pq[t - 1] * (1 + A.fd);
-      inv_den[t - 1] = 1.0 / (pq[t - 1] * A.fd);  // perturbed value in the denominator, MCMC.py:264
-    }
-    L[t].inv_dc = 1.0 / pq[0]; L[t].kprime = (1e-2 * 10) / pq[0]; L[t].inv_a = 1.0 / pq[1]; L[t].b = pq[2];
-    y[t][0] = K.mu0; y[t][1] = pq[0] / K.V_ref; y[t][2] = K.V_ref;
-    x[t] = K.t0; hc[t] = 0.0; vprev[t] = K.V_ref; failed[t] = false; have_kf[t] = false;
-  }
-  double xtx[D * D];
-#pragma unroll
-  for (int e = 0; e < D * D; ++e) xtx[e] = 0.0;
-  double ssq = 0.0;
-  if (active) { const double d0 = K.data[0]; ssq = d0 * d0; }
-  const double *ld = lds + rsf::dp::lds_data_offset_dp(K);
-  const double delta_t = K.dt;
-  for (int k0 = 1; k0 < K.nout; k0 += K.kc) {
-    const int kn = min(K.kc, K.nout - k0);
-    rsf::dp::stage_chunk_dp(lds, K, k0, kn);
-    if (!active) continue;
-    for (int kk = 0; kk < kn; ++kk) {
-      double ak[D + 1];
-#pragma unroll
-      for (int t = 0; t <= D; ++t) {
-        ak[t] = 0.0;
-        if (!failed[t]) {
-          failed[t] = !rsf::dp::call<DAMP>(K, L[t], lds + rsf::dp::kTab * kk, x[t], x[t] + delta_t, y[t], hc[t], kfs[t], bfs[t], have_kf[t]);
-          ak[t] = (y[t][2] - vprev[t]) * K.inv_dt;
-          vprev[t] = y[t][2];
-        }
-      }
-      const double r = ak[0] - ld[kk];
-      ssq += r * r;
-      double xs[D];
-#pragma unroll
-      for (int p = 0; p < D; ++p) xs[p] = (ak[p + 1] - ak[0]) * inv_den[p];
-#pragma unroll
-      for (int p = 0; p < D; ++p)
-#pragma unroll
-        for (int r2 = 0; r2 < D; ++r2) xtx[p * D + r2] += xs[p] * xs[r2];
-    }
-  }
-  if (active) {
-    const double std2 = ssq * A.inv_dof;
-    double xi[D * D];
-    rsf::sym_inverse<D>(xtx, xi);
-#pragma unroll
-    for (int e = 0; e < D * D; ++e) A.V[i * D * D + e] = std2 * xi[e];  // MCMC.py:266
-    A.std2[i] = std2;
-    A.ssq[i] = ssq;
-  }
-}
-
-// float32 mode: the sampler compares sums of squares from float32 solves, so the initial SSq (computed by the
-// float64 init kernel together with the float64-only sensitivities) is replaced by its float32 value.
-template <int D, bool DAMP>
-__global__ void __launch_bounds__(kMaxBlock) ssq32_kernel(Consts K, int64_t C, const double *q, double *ssq) {
-  extern __shared__ __attribute__((aligned(16))) double lds[];
-  rsf::select_group(K);
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const bool active = i < C;
-  const double dc = active ? q[i * D] : 1.0;
-  const double a = (active && D == 3) ? q[i * D + 1] : K.a_def, b = (active && D == 3) ? q[i * D + 2] : K.b_def;
-  const double s = rsf::f32::solve32<DAMP, true, false>(reinterpret_cast<float *>(lds), K, false, active, dc, a, b, nullptr, 0);
-  if (active) ssq[i] = s;
-}
-
-struct McmcArgs {
-  int64_t C, chain_offset, n_iters, iter_base;
-  uint64_t seed;
-  double n0, shape;
-  double gd, gc;  // Marsaglia-Tsang constants of Gamma(shape): d = shape - 1/3, c = 1/sqrt(9 d)
-  double lo[RSF_MAX_PARAMS], hi[RSF_MAX_PARAMS];
-  int32_t adapt_mode, adapt_interval;
-  double dict_scale;  // 2.38^2 / len(qpriors.keys()), MCMC.py:200 (reference_dict mode)
-  double *q, *ssq, *std2, *V;           // per-chain state
-  double *wref, *wsum, *wsq;            // adaptation window (shifted sums)
-  int32_t *wn;
-  unsigned long long *stats;            // [3] accepted, evaluated, non-finite
-  const double *z, *u, *g;              // replay variates (REPLAY only)
-  double *tq, *ts;                      // traces, iteration-major
-  uint8_t *ta;
-};
-
-template <int D, bool DAMP, bool REPLAY, int MODE>
-__global__ void __launch_bounds__(kMaxBlock, MODE == DOP853 ? RSF_DP_MIN_BLOCKS : RSF_MIN_BLOCKS) mcmc_kernel(Consts K, McmcArgs A) {
-  extern __shared__ __attribute__((aligned(16))) double lds[];
-  rsf::select_group(K);
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const bool valid = i < A.C;
-  const uint64_t gid = (uint64_t)(A.chain_offset + i);  // RNG is keyed by the GLOBAL chain id
-  const bool resident = K.nchunks == 1;
-
-  double q[D], V[D * D];
-  double ssq = 0.0, std2 = 1.0;
-#pragma unroll
-  for (int p = 0; p < D; ++p) q[p] = 1.0;
-#pragma unroll
-  for (int e = 0; e < D * D; ++e) V[e] = 0.0;
-  // adaptation window (shifted sums over the last adapt_interval samples): 3 + 3 + 9 doubles for D = 3, and the proposal
-  // covariance V, 9 more — forty-eight registers that would stay live across the forward solve, where the register budget is
-  // spent on the integrator.  For D = 3 both therefore live in their HBM arrays: V is read where the proposal is formed, the
-  // window is read-modified-written once per proposal (~40 accesses against 4000 RK4 steps); D = 1 keeps its values in registers.
-  constexpr bool kWinRegs = D == 1;
-  double wr[D], ws[D], wq[D * D];
-  int32_t wn = 0;
-  if (valid) {
-#pragma unroll
-    for (int p = 0; p < D; ++p) q[p] = A.q[i * D + p];
-    if (kWinRegs) {
-#pragma unroll
-      for (int e = 0; e < D * D; ++e) V[e] = A.V[i * D * D + e];
-    }
-    ssq = A.ssq[i];
-    std2 = A.std2[i];
-  }
-  auto load_window = [&]() {
-#pragma unroll
-    for (int p = 0; p < D; ++p) { wr[p] = A.wref[i * D + p]; ws[p] = A.wsum[i * D + p]; }
-#pragma unroll
-    for (int e = 0; e < D * D; ++e) wq[e] = A.wsq[i * D * D + e];
-    wn = A.wn[i];
-  };
-  auto store_window = [&]() {
-#pragma unroll
-    for (int p = 0; p < D; ++p) { A.wref[i * D + p] = wr[p]; A.wsum[i * D + p] = ws[p]; }
-#pragma unroll
-    for (int e = 0; e < D * D; ++e) A.wsq[i * D * D + e] = wq[e];
-    A.wn[i] = wn;
-  };
-  if (kWinRegs && A.adapt_mode != RSF_ADAPT_NONE && valid) load_window();
-  uint32_t n_acc = 0, n_eval = 0, n_nonfinite = 0;
-
-  float *lds32 = reinterpret_cast<float *>(lds);
-  if (resident) {
-    if constexpr (MODE == RK4_F32) rsf::f32::stage_chunk32(lds32, K, 1, K.nout - 1);
-    else if constexpr (MODE == DOP853) rsf::dp::stage_chunk_dp(lds, K, 1, K.nout - 1);
-    else rsf::stage_chunk(lds, K, 1, K.nout - 1);
-  }
-
-  for (int64_t n = 0; n < A.n_iters; ++n) {
-    const uint32_t it = (uint32_t)(A.iter_base + n);
-    const int64_t row = n * A.C + i;
-    // ---- proposal, MCMC.py:497 ----
-    double z[4] = {0.0, 0.0, 0.0, 0.0};
-    if (REPLAY) {
-      if (valid) {
-#pragma unroll
-        for (int p = 0; p < D; ++p) z[p] = A.z[row * D + p];
-      }
-    } else {
-      uint32_t w[4];
-      rsf::draw_words(A.seed, gid, it, rsf::SLOT_Z01, w);
-      rsf::normal_pair(w, z[0], z[1]);
-      if (D > 2) {
-        rsf::draw_words(A.seed, gid, it, rsf::SLOT_Z2, w);
-        rsf::normal_pair(w, z[2], z[3]);
-      }
-    }
-    double Lc[D * D], qn[D];
-    if (!kWinRegs && valid) {  // D = 3: the proposal covariance is read where it is used instead of living in 18 registers
-#pragma unroll
-      for (int e = 0; e < D * D; ++e) V[e] = A.V[i * D * D + e];
-    }
-    rsf::chol_lower<D>(V, Lc);
-    bool inb = valid;
-#pragma unroll
-    for (int p = 0; p < D; ++p) {
-      double s = q[p];
-#pragma unroll
-      for (int r = 0; r <= p; ++r) s += Lc[p * D + r] * z[r];
-      qn[p] = s;
-      inb = inb && (s > A.lo[p]) && (s < A.hi[p]);  // strict box, MCMC.py:318-320
-    }
-    // ---- likelihood: forward solve only for in-bounds proposals, MCMC.py:322-324 ----
-    double an = K.a_def, bn = K.b_def;
-    if constexpr (D == 3) { an = qn[1]; bn = qn[2]; }
-    double ssqn = 0.0;
-    // (a wave with no in-bounds lane skips the solve when the tables are resident: no barrier inside)
-    if (!resident || __any(inb)) {
-      if constexpr (MODE == RK4_F32) ssqn = rsf::f32::solve32<DAMP, true, false>(lds32, K, resident, inb, qn[0], an, bn, nullptr, 0);
-      else if constexpr (MODE == DOP853) ssqn = rsf::dp::solve<DAMP, true, false>(lds, K, resident, inb, qn[0], an, bn, nullptr, 0);
-      else ssqn = rsf::solve<DAMP, true, false, (D == 1 ? 2 : RSF_D3_TRIP) * RSF_TIGHT_UNROLL>(lds, K, resident, inb, qn[0], an, bn, nullptr, 0);
-    }
-    // ---- accept / reject, MCMC.py:327-333 ----
-    bool accept = false;
-    if (inb) {
-      double u;
-      if (REPLAY) {
-        u = A.u[row];
-      } else {
-        uint32_t w[4];
-        rsf::draw_words(A.seed, gid, it, rsf::SLOT_U, w);
-        u = rsf::u53(w[0], w[1]);
-      }
-      // (replaying recorded variates follows the reference's arithmetic to the last bit: IEEE division, libm-grade log;
-      //  the sampler proper uses the kernel's own reciprocal and log — the same value to ~1 ulp)
-      const double logalpha = fmin(REPLAY ? 0.5 * (ssq - ssqn) / std2 : (0.5 * (ssq - ssqn)) * rsf::fm::rcp(std2), 0.0);
-      accept = logalpha > (REPLAY ? log(u) : rsf::rng_log(u));  // NaN compares false => reject
-      ++n_eval;
-      if (!isfinite(ssqn)) ++n_nonfinite;
-      if (accept) {
-        ssq = ssqn;
-#pragma unroll
-        for (int p = 0; p < D; ++p) q[p] = qn[p];
-        ++n_acc;
-      }
-    }
-    // ---- sigma^2 Gibbs update with the post-accept SSq, MCMC.py:158-160 ----
-    if (valid) {
-      const double bval = 0.5 * (A.n0 * std2 + ssq);
-      const double g = REPLAY ? A.g[row] : rsf::gamma_draw(A.seed, gid, it, A.gd, A.gc);
-      std2 = REPLAY ? bval / g : bval * rsf::fm::rcp(g);
-      if (A.tq) {
-#pragma unroll
-        for (int p = 0; p < D; ++p) A.tq[row * D + p] = q[p];
-      }
-      if (A.ts) A.ts[row] = std2;
-      if (A.ta) A.ta[row] = accept ? 1 : 0;
-    }
-    // ---- adaptation, MCMC.py:200-204, 523-527 ----
-    if (A.adapt_mode != RSF_ADAPT_NONE && valid) {
-      if (!kWinRegs) load_window();
-#pragma unroll
-      for (int p = 0; p < D; ++p) {
-        ws[p] += q[p] - wr[p];
-#pragma unroll
-        for (int r = 0; r < D; ++r) wq[p * D + r] += (q[p] - wr[p]) * (q[r] - wr[r]);
-      }
-      ++wn;
-      if ((A.iter_base + n + 1) % A.adapt_interval == 0) {
-        if (wn >= 2) {
-          const double nn = (double)wn;
-          double Vn[D * D], Ln[D * D];
-          if (A.adapt_mode == RSF_ADAPT_REFERENCE_DICT) {
-            // d := len(qpriors.keys()) (2 for {1: lo, 2: hi}), and the Cholesky FACTOR becomes the next covariance
-            Vn[0] = A.dict_scale * ((wq[0] - ws[0] * ws[0] / nn) / (nn - 1.0));
-            if (rsf::chol_lower<1>(Vn, Ln)) V[0] = Ln[0];
-          } else {
-#pragma unroll
-            for (int p = 0; p < D; ++p)
-#pragma unroll
-              for (int r = 0; r < D; ++r)
-                Vn[p * D + r] = 2.38 * 2.38 / (double)D * ((wq[p * D + r] - ws[p] * ws[r] / nn) / (nn - 1.0));
-            if (rsf::chol_lower<D>(Vn, Ln)) {
-#pragma unroll
-              for (int e = 0; e < D * D; ++e) {
-                if (kWinRegs) V[e] = Vn[e];
-                else A.V[i * D * D + e] = Vn[e];
-              }
-            }
-          }
-        }
-        wn = 0;
-#pragma unroll
-        for (int p = 0; p < D; ++p) { wr[p] = q[p]; ws[p] = 0.0; }
-#pragma unroll
-        for (int e = 0; e < D * D; ++e) wq[e] = 0.0;
-      }
-      if (!kWinRegs) store_window();
-    }
-  }
-
-  if (valid) {
-#pragma unroll
-    for (int p = 0; p < D; ++p) A.q[i * D + p] = q[p];
-    if (kWinRegs) {
-#pragma unroll
-      for (int e = 0; e < D * D; ++e) A.V[i * D * D + e] = V[e];
-    }
-    A.ssq[i] = ssq;
-    A.std2[i] = std2;
-    if (kWinRegs && A.adapt_mode != RSF_ADAPT_NONE) store_window();
-  }
-  // statistics: wave shuffle reduction, one atomic per wave and counter
-  const unsigned long long s0 = rsf::wave_sum(n_acc), s1 = rsf::wave_sum(n_eval), s2 = rsf::wave_sum(n_nonfinite);
-  if ((threadIdx.x & 63) == 0) {
-    if (s0) atomicAdd(&A.stats[0], s0);
-    if (s1) atomicAdd(&A.stats[1], s1);
-    if (s2) atomicAdd(&A.stats[2], s2);
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
-// posterior post-processing on pooled samples (RSF.plot_dist, RSF.py:717-746)
-// ---------------------------------------------------------------------------------------------
-constexpr int kPoolBlocks = 1024;  // 4 workgroups per CU; partials are combined deterministically (no atomics)
-
-struct PoolPartial {
-  double cnt, sum, sumsq, mn, mx;  // sums are taken about a common shift for stability
-};
-
-__global__ void __launch_bounds__(kMaxBlock)
-pool_moments_kernel(int64_t n, const double *__restrict__ x, int64_t stride, double shift, PoolPartial *__restrict__ part) {
-  __shared__ PoolPartial sh[kMaxBlock / 64];
-  double cnt = 0.0, sum = 0.0, sumsq = 0.0, mn = INFINITY, mx = -INFINITY;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-    const double v = x[i * stride], dlt = v - shift;
-    cnt += 1.0; sum += dlt; sumsq = __builtin_fma(dlt, dlt, sumsq);
-    mn = fmin(mn, v); mx = fmax(mx, v);
-  }
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    cnt += __shfl_down(cnt, off, 64); sum += __shfl_down(sum, off, 64); sumsq += __shfl_down(sumsq, off, 64);
-    mn = fmin(mn, __shfl_down(mn, off, 64)); mx = fmax(mx, __shfl_down(mx, off, 64));
-  }
-  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = {cnt, sum, sumsq, mn, mx};
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    PoolPartial p = sh[0];
-    for (unsigned w = 1; w < blockDim.x / 64; ++w) {
-      p.cnt += sh[w].cnt; p.sum += sh[w].sum; p.sumsq += sh[w].sumsq; p.mn = fmin(p.mn, sh[w].mn); p.mx = fmax(p.mx, sh[w].mx);
-    }
-    part[blockIdx.x] = p;
-  }
-}
-
-// Fixed-bin histogram (rsf_pool_histogram): HBM-bound, one pass.  Every workgroup counts into an LDS copy of the bins
-// (ds_add_u32), then adds its non-empty bins to the global 64-bit counters — integer atomics, so the result does not
-// depend on the order of arrival.  Bin index = floor((x - lo) * scale), scale = nbins/(hi - lo) from the host: one
-// subtraction and one product, no contraction possible, hence bit-identical to the CPU restatement.
-constexpr int kHistMaxBins = 4096;
-
-__device__ __forceinline__ int hist_bin(double v, double lo, double hi, double scale, int nbins) {
-  if (v < lo) return 0;
-  if (!(v <= hi)) return nbins + 1;                      // above hi, or NaN
-  const int b = (int)floor((v - lo) * scale);
-  return 1 + (b < nbins ? b : nbins - 1);                // v == hi (or rounding at the upper edge) -> last bin
-}
-
-__global__ void __launch_bounds__(kMaxBlock)
-pool_hist_kernel(int64_t n, const double *__restrict__ x, int64_t stride, int nbins, double lo, double hi, double scale,
-                 unsigned long long *__restrict__ counts) {
-  extern __shared__ unsigned int hbins[];
-  for (int b = threadIdx.x; b < nbins + 2; b += blockDim.x) hbins[b] = 0u;
-  __syncthreads();
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-    atomicAdd(&hbins[hist_bin(x[i * stride], lo, hi, scale, nbins)], 1u);
-  __syncthreads();
-  for (int b = threadIdx.x; b < nbins + 2; b += blockDim.x)
-    if (hbins[b]) atomicAdd(&counts[b], (unsigned long long)hbins[b]);
-}
-
-__global__ void __launch_bounds__(kMaxBlock) pool_hist_finish_kernel(int nb, const unsigned long long *__restrict__ counts, double *__restrict__ out) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b < nb) out[b] = (double)counts[b];
-}
-
-// Each workgroup owns a contiguous slice of the samples, streamed through LDS in tiles; every thread
-// accumulates the kernel sum of its grid points over the slice (LDS broadcast reads).  partial[block][m].
-constexpr int kKdeTile = 1024;
-
-__global__ void __launch_bounds__(kMaxBlock)
-pool_kde_kernel(int64_t n, const double *__restrict__ x, int64_t stride, int m, const double *__restrict__ grid, double inv2c,
-                double *__restrict__ partial) {
-  __shared__ double tile[kKdeTile];
-  const int64_t per = (n + gridDim.x - 1) / gridDim.x, lo = (int64_t)blockIdx.x * per, hi = min(n, lo + per);
-  for (int j0 = 0; j0 < m; j0 += blockDim.x) {
-    const int j = j0 + threadIdx.x;
-    const double g = j < m ? grid[j] : 0.0;
-    double acc = 0.0;
-    for (int64_t t0 = lo; t0 < hi; t0 += kKdeTile) {
-      const int tn = (int)min((int64_t)kKdeTile, hi - t0);
-      __syncthreads();
-      for (int t = threadIdx.x; t < tn; t += blockDim.x) tile[t] = x[(t0 + t) * stride];
-      __syncthreads();
-      for (int t = 0; t < tn; ++t) {
-        const double dlt = g - tile[t];
-        acc += rsf::fm::exp(-dlt * dlt * inv2c);
-      }
-    }
-    if (j < m) partial[(int64_t)blockIdx.x * m + j] = acc;
-  }
-}
-
-__global__ void __launch_bounds__(kMaxBlock)
-pool_kde_reduce_kernel(int nblocks, int m, const double *__restrict__ partial, double norm, double *__restrict__ density) {
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= m) return;
-  double acc = 0.0;
-  for (int b = 0; b < nblocks; ++b) acc += partial[(int64_t)b * m + j];  // fixed order: reproducible
-  density[j] = acc * norm;
-}
-
-// out[0..3] = philox words (as doubles are not used here): layout documented at the call sites
-__global__ void probe_philox_kernel(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
-                                    uint32_t *out) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) {
-    uint32_t w[4];
-    rsf::philox4x32_10(c0, c1, c2, c3, k0, k1, w);
-    for (int j = 0; j < 4; ++j) out[j] = w[j];
-  }
-}
-
-// out = { z0, z1, z2, u, g }
-__global__ void probe_draws_kernel(uint64_t seed, uint64_t chain, uint32_t iter, int d, double shape, double *out) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) {
-    uint32_t w[4];
-    double z[4] = {0, 0, 0, 0};
-    rsf::draw_words(seed, chain, iter, rsf::SLOT_Z01, w);
-    rsf::normal_pair(w, z[0], z[1]);
-    if (d > 2) { rsf::draw_words(seed, chain, iter, rsf::SLOT_Z2, w); rsf::normal_pair(w, z[2], z[3]); }
-    rsf::draw_words(seed, chain, iter, rsf::SLOT_U, w);
-    out[0] = z[0]; out[1] = z[1]; out[2] = z[2];
-    out[3] = rsf::u53(w[0], w[1]);
-    out[4] = rsf::gamma_draw(seed, chain, iter, shape - 1.0 / 3.0, 1.0 / sqrt(9.0 * (shape - 1.0 / 3.0)));
-  }
-}
 
 // ---------------------------------------------------------------------------------------------
 // host side
@@ -753,6 +175,22 @@ Consts make_consts(const rsf_ctx *c, const double *data) {
 
 unsigned grid_for(const rsf_ctx *c, int64_t n) { return (unsigned)((n + c->block - 1) / c->block); }
 
+// LDS of a sampler launch: the table chunk, and behind it the per-lane Cholesky factors of a three-parameter chain
+// (six doubles per lane, mcmc_kernel)
+size_t mcmc_lds_bytes(const rsf_ctx *c) {
+  return c->lds_bytes + (c->mc.n_params == 3 ? (size_t)6 * sizeof(double) * (size_t)c->block : 0);
+}
+
+// [n][d] (the C ABI's layout) <-> [d][n] (the kernels' structure of arrays); both device pointers, on the ctx stream
+int transpose(rsf_ctx *c, int64_t n, int d, const double *src, double *dst, bool to_soa) {
+  if (d == 1) {
+    if (src != dst) HIP_TRY(hipMemcpyAsync(dst, src, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    return RSF_OK;
+  }
+  hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)((n + kMaxBlock - 1) / kMaxBlock)), dim3(kMaxBlock), 0, c->stream, n, d, src, dst, to_soa);
+  return RSF_OK;
+}
+
 int mode_of(const rsf_ctx *c) {
   return (c->m.flags & RSF_FLAG_DOP853) ? DOP853 : ((c->m.flags & RSF_FLAG_FP32_SOLVE) ? RK4_F32 : RK4_F64);
 }
@@ -761,9 +199,9 @@ template <int D, bool DAMP, int MODE>
 int launch_mcmc(rsf_ctx *c, const Consts &K, const McmcArgs &A, bool replay) {
   const dim3 grid(grid_for(c, A.C)), block(c->block);
   if (replay)
-    hipLaunchKernelGGL((mcmc_kernel<D, DAMP, true, MODE>), grid, block, c->lds_bytes, c->stream, K, A);
+    hipLaunchKernelGGL((mcmc_kernel<D, DAMP, true, MODE>), grid, block, mcmc_lds_bytes(c), c->stream, K, A);
   else
-    hipLaunchKernelGGL((mcmc_kernel<D, DAMP, false, MODE>), grid, block, c->lds_bytes, c->stream, K, A);
+    hipLaunchKernelGGL((mcmc_kernel<D, DAMP, false, MODE>), grid, block, mcmc_lds_bytes(c), c->stream, K, A);
   return RSF_OK;
 }
 
@@ -876,7 +314,7 @@ int run_replay_graph(rsf_ctx *c, const Consts &K, McmcArgs A, const double *z, c
   const size_t out_off = (in_bytes + 255) & ~(size_t)255, total = out_off + ((out_bytes + 255) & ~(size_t)255);
   const void *fn = replay_kernel(c);
   char *hb = (char *)G.host, *db = (char *)G.dev;
-  const bool rebuild = !G.exec || G.C != A.C || G.d != d || G.fn != fn || G.lds != c->lds_bytes || G.block != c->block;
+  const bool rebuild = !G.exec || G.C != A.C || G.d != d || G.fn != fn || G.lds != mcmc_lds_bytes(c) || G.block != c->block;
   if (rebuild) {
     release_replay_graph(c);
     HIP_TRY(hipHostMalloc(&G.host, total, hipHostMallocDefault));
@@ -892,7 +330,7 @@ int run_replay_graph(rsf_ctx *c, const Consts &K, McmcArgs A, const double *z, c
   hipKernelNodeParams kp{};
   kp.func = const_cast<void *>(fn);
   kp.gridDim = dim3(grid_for(c, A.C)); kp.blockDim = dim3(c->block);
-  kp.sharedMemBytes = (unsigned)c->lds_bytes;
+  kp.sharedMemBytes = (unsigned)mcmc_lds_bytes(c);
   kp.kernelParams = params;
   kp.extra = nullptr;
   if (rebuild) {
@@ -902,7 +340,7 @@ int run_replay_graph(rsf_ctx *c, const Consts &K, McmcArgs A, const double *z, c
     HIP_TRY(hipGraphAddKernelNode(&G.kernel, G.graph, &h2d, 1, &kp));
     HIP_TRY(hipGraphAddMemcpyNode1D(&d2h, G.graph, &G.kernel, 1, hb + out_off, db + out_off, out_bytes, hipMemcpyDeviceToHost));
     HIP_TRY(hipGraphInstantiate(&G.exec, G.graph, nullptr, nullptr, 0));
-    G.C = A.C; G.d = d; G.fn = fn; G.lds = c->lds_bytes; G.block = c->block;
+    G.C = A.C; G.d = d; G.fn = fn; G.lds = mcmc_lds_bytes(c); G.block = c->block;
   } else {
     HIP_TRY(hipGraphExecKernelNodeSetParams(G.exec, G.kernel, &kp));
   }
@@ -937,6 +375,7 @@ int run_mcmc(rsf_ctx *c, int64_t n_iters, const double *z, const double *u, cons
   for (int p = 0; p < RSF_MAX_PARAMS; ++p) { A.lo[p] = c->mc.lo[p]; A.hi[p] = c->mc.hi[p]; }
   A.adapt_mode = c->mc.adapt_mode; A.adapt_interval = c->mc.adapt_interval > 0 ? c->mc.adapt_interval : 1;
   A.dict_scale = 2.38 * 2.38 / (double)(c->mc.prior_len > 0 ? c->mc.prior_len : 2);
+  A.lc_off = (int32_t)(c->lds_bytes / sizeof(double));
   A.q = (double *)c->q.p; A.ssq = (double *)c->ssq.p; A.std2 = (double *)c->std2.p; A.V = (double *)c->V.p;
   A.wref = (double *)c->wref.p; A.wsum = (double *)c->wsum.p; A.wsq = (double *)c->wsq.p; A.wn = (int32_t *)c->wn.p;
   A.stats = (unsigned long long *)c->stats.p;
@@ -978,6 +417,9 @@ struct Rccl {
   void *h = nullptr;
   decltype(&ncclGetUniqueId) get_unique_id = nullptr;
   decltype(&ncclCommInitRank) comm_init_rank = nullptr;
+  decltype(&ncclCommInitAll) comm_init_all = nullptr;
+  decltype(&ncclGroupStart) group_start = nullptr;
+  decltype(&ncclGroupEnd) group_end = nullptr;
   decltype(&ncclCommDestroy) comm_destroy = nullptr;
   decltype(&ncclAllGather) all_gather = nullptr;
   decltype(&ncclAllReduce) all_reduce = nullptr;
@@ -999,11 +441,16 @@ void bind_rccl(Rccl &r) {
   if (!r.h) return;
   r.get_unique_id = (decltype(r.get_unique_id))dlsym(r.h, "ncclGetUniqueId");
   r.comm_init_rank = (decltype(r.comm_init_rank))dlsym(r.h, "ncclCommInitRank");
+  r.comm_init_all = (decltype(r.comm_init_all))dlsym(r.h, "ncclCommInitAll");
+  r.group_start = (decltype(r.group_start))dlsym(r.h, "ncclGroupStart");
+  r.group_end = (decltype(r.group_end))dlsym(r.h, "ncclGroupEnd");
   r.comm_destroy = (decltype(r.comm_destroy))dlsym(r.h, "ncclCommDestroy");
   r.all_gather = (decltype(r.all_gather))dlsym(r.h, "ncclAllGather");
   r.all_reduce = (decltype(r.all_reduce))dlsym(r.h, "ncclAllReduce");
   r.error_string = (decltype(r.error_string))dlsym(r.h, "ncclGetErrorString");
-  if (!r.get_unique_id || !r.comm_init_rank || !r.comm_destroy || !r.all_gather || !r.all_reduce || !r.error_string) r.h = nullptr;
+  if (!r.get_unique_id || !r.comm_init_rank || !r.comm_init_all || !r.group_start || !r.group_end || !r.comm_destroy || !r.all_gather ||
+      !r.all_reduce || !r.error_string)
+    r.h = nullptr;
 }
 
 const Rccl *rccl() {  // bound once, whichever thread asks first
@@ -1242,8 +689,10 @@ int rsf_mcmc_init(rsf_ctx *c, const rsf_mcmc_config *cfg, const double *q0, cons
   if ((rc = ensure(c->stats, 3 * sizeof(unsigned long long)))) return rc;
   const hipMemcpyKind kind = host_mem(c) ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
   HIP_TRY(hipMemcpyAsync(c->data.p, data, data_bytes, kind, c->stream));
-  HIP_TRY(hipMemcpyAsync(c->q.p, q0, cb * d, kind, c->stream));
-  HIP_TRY(hipMemcpyAsync(c->wref.p, q0, cb * d, kind, c->stream));
+  const void *dq0;
+  if ((rc = stage_in(c, 0, q0, cb * d, &dq0))) return rc;
+  if ((rc = transpose(c, C, d, (const double *)dq0, (double *)c->q.p, true))) return rc;
+  HIP_TRY(hipMemcpyAsync(c->wref.p, c->q.p, cb * d, hipMemcpyDeviceToDevice, c->stream));
   HIP_TRY(hipMemsetAsync(c->wsum.p, 0, cb * d, c->stream));
   HIP_TRY(hipMemsetAsync(c->wsq.p, 0, cb * d * d, c->stream));
   HIP_TRY(hipMemsetAsync(c->wn.p, 0, (size_t)C * sizeof(int32_t), c->stream));
@@ -1298,10 +747,17 @@ int rsf_mcmc_get_state(rsf_ctx *c, double *q, double *ssq, double *std2, double 
   const int d = c->mc.n_params;
   const size_t cb = (size_t)c->mc.n_chains * sizeof(double);
   const hipMemcpyKind kind = host_mem(c) ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
-  if (q) HIP_TRY(hipMemcpyAsync(q, c->q.p, cb * d, kind, c->stream));
+  const int64_t C = c->mc.n_chains;
+  void *dq, *dV;
+  int rc;
+  if ((rc = stage_out(c, 0, q, cb * d, &dq))) return rc;
+  if ((rc = stage_out(c, 1, V, cb * d * d, &dV))) return rc;
+  if (q && (rc = transpose(c, C, d, (const double *)c->q.p, (double *)dq, false))) return rc;
+  if (V && (rc = transpose(c, C, d * d, (const double *)c->V.p, (double *)dV, false))) return rc;
+  if ((rc = copy_back(c, 0, q, cb * d))) return rc;
+  if ((rc = copy_back(c, 1, V, cb * d * d))) return rc;
   if (ssq) HIP_TRY(hipMemcpyAsync(ssq, c->ssq.p, cb, kind, c->stream));
   if (std2) HIP_TRY(hipMemcpyAsync(std2, c->std2.p, cb, kind, c->stream));
-  if (V) HIP_TRY(hipMemcpyAsync(V, c->V.p, cb * d * d, kind, c->stream));
   return finish(c);
 }
 
@@ -1312,10 +768,15 @@ int rsf_mcmc_set_state(rsf_ctx *c, const double *q, const double *ssq, const dou
   const int d = c->mc.n_params;
   const size_t cb = (size_t)c->mc.n_chains * sizeof(double);
   const hipMemcpyKind kind = host_mem(c) ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
-  if (q) HIP_TRY(hipMemcpyAsync(c->q.p, q, cb * d, kind, c->stream));
+  const int64_t C = c->mc.n_chains;
+  const void *dq, *dV;
+  int rc;
+  if ((rc = stage_in(c, 0, q, cb * d, &dq))) return rc;
+  if ((rc = stage_in(c, 1, V, cb * d * d, &dV))) return rc;
+  if (q && (rc = transpose(c, C, d, (const double *)dq, (double *)c->q.p, true))) return rc;
+  if (V && (rc = transpose(c, C, d * d, (const double *)dV, (double *)c->V.p, true))) return rc;
   if (ssq) HIP_TRY(hipMemcpyAsync(c->ssq.p, ssq, cb, kind, c->stream));
   if (std2) HIP_TRY(hipMemcpyAsync(c->std2.p, std2, cb, kind, c->stream));
-  if (V) HIP_TRY(hipMemcpyAsync(c->V.p, V, cb * d * d, kind, c->stream));
   return finish(c);
 }
 
@@ -1506,6 +967,98 @@ int rsf_pool_allreduce_sum(rsf_ctx *c, double *buf, int64_t count) {
   RCCL_TRY(R, R->all_reduce(ds, (void *)ds, (size_t)count, ncclFloat64, ncclSum, c->comm, c->stream));
   if (host_mem(c)) HIP_TRY(hipMemcpyAsync(buf, ds, bytes, hipMemcpyDeviceToHost, c->stream));
   return finish(c);
+}
+
+// ---- single-process form: one ctx per device, one host thread drives them all (ncclCommInitAll + grouped calls) ----
+namespace {
+
+int check_group(rsf_ctx *const *ctxs, int32_t n, const char *who, bool need_comm) {
+  if (!ctxs || n < 1) return fail(RSF_ERR_INVALID, "%s: bad argument", who);
+  for (int32_t i = 0; i < n; ++i) {
+    if (!ctxs[i]) return fail(RSF_ERR_INVALID, "%s: ctxs[%d] is NULL", who, i);
+    for (int32_t j = 0; j < i; ++j)
+      if (ctxs[j] == ctxs[i]) return fail(RSF_ERR_INVALID, "%s: ctxs[%d] and ctxs[%d] are the same ctx", who, j, i);
+    if (need_comm && (ctxs[i]->world != n || ctxs[i]->rank != i || !ctxs[i]->comm))
+      return fail(RSF_ERR_STATE, "%s: ctxs[%d] is not rank %d of a %d-rank group made by rsf_comm_init_all", who, i, i, n);
+  }
+  return RSF_OK;
+}
+
+}  // namespace
+
+int rsf_comm_init_all(rsf_ctx *const *ctxs, int32_t n) {
+  int rc = check_group(ctxs, n, "rsf_comm_init_all", false);
+  if (rc) return rc;
+  for (int32_t i = 0; i < n; ++i)
+    if (ctxs[i]->world) return fail(RSF_ERR_STATE, "rsf_comm_init_all: ctxs[%d] already has a communicator (rsf_comm_destroy first)", i);
+  const Rccl *R = rccl();
+  if (!R) return fail(RSF_ERR_UNSUPPORTED, "rsf_comm_init_all: RCCL (librccl.so) could not be loaded");
+  std::vector<int> devs(n);
+  std::vector<ncclComm_t> comms(n, nullptr);
+  for (int32_t i = 0; i < n; ++i) devs[i] = ctxs[i]->device;
+  RCCL_TRY(R, R->comm_init_all(comms.data(), n, devs.data()));
+  for (int32_t i = 0; i < n; ++i) { ctxs[i]->comm = comms[i]; ctxs[i]->world = n; ctxs[i]->rank = i; }
+  return RSF_OK;
+}
+
+int rsf_pool_allgather_all(rsf_ctx *const *ctxs, int32_t n, const double *const *send, int64_t count, double *const *recv) {
+  int rc = check_group(ctxs, n, "rsf_pool_allgather_all", true);
+  if (rc) return rc;
+  if (!send || !recv || count < 1) return fail(RSF_ERR_INVALID, "rsf_pool_allgather_all: bad argument");
+  for (int32_t i = 0; i < n; ++i)
+    if (!send[i] || !recv[i]) return fail(RSF_ERR_INVALID, "rsf_pool_allgather_all: send[%d] / recv[%d] is NULL", i, i);
+  const Rccl *R = rccl();
+  const size_t bytes = (size_t)count * sizeof(double);
+  std::vector<const void *> ds(n);
+  std::vector<void *> dr(n);
+  for (int32_t i = 0; i < n; ++i) {
+    DeviceGuard guard(ctxs[i]->device);
+    if (!guard.ok) return fail(RSF_ERR_DEVICE, "rsf_pool_allgather_all: cannot select device %d", ctxs[i]->device);
+    if ((rc = stage_in(ctxs[i], 0, send[i], bytes, &ds[i]))) return rc;
+    if ((rc = stage_out(ctxs[i], 1, recv[i], bytes * (size_t)n, &dr[i]))) return rc;
+  }
+  RCCL_TRY(R, R->group_start());
+  for (int32_t i = 0; i < n; ++i) {
+    DeviceGuard guard(ctxs[i]->device);
+    const ncclResult_t e = R->all_gather(ds[i], dr[i], (size_t)count, ncclFloat64, ctxs[i]->comm, ctxs[i]->stream);
+    if (e != ncclSuccess) { (void)R->group_end(); return fail(RSF_ERR_DEVICE, "ncclAllGather (rank %d) -> %s", i, R->error_string(e)); }
+  }
+  RCCL_TRY(R, R->group_end());
+  for (int32_t i = 0; i < n; ++i) {
+    DeviceGuard guard(ctxs[i]->device);
+    if ((rc = copy_back(ctxs[i], 1, recv[i], bytes * (size_t)n))) return rc;
+    if ((rc = finish(ctxs[i]))) return rc;
+  }
+  return RSF_OK;
+}
+
+int rsf_pool_allreduce_sum_all(rsf_ctx *const *ctxs, int32_t n, double *const *bufs, int64_t count) {
+  int rc = check_group(ctxs, n, "rsf_pool_allreduce_sum_all", true);
+  if (rc) return rc;
+  if (!bufs || count < 1) return fail(RSF_ERR_INVALID, "rsf_pool_allreduce_sum_all: bad argument");
+  for (int32_t i = 0; i < n; ++i)
+    if (!bufs[i]) return fail(RSF_ERR_INVALID, "rsf_pool_allreduce_sum_all: bufs[%d] is NULL", i);
+  const Rccl *R = rccl();
+  const size_t bytes = (size_t)count * sizeof(double);
+  std::vector<const void *> ds(n);
+  for (int32_t i = 0; i < n; ++i) {
+    DeviceGuard guard(ctxs[i]->device);
+    if (!guard.ok) return fail(RSF_ERR_DEVICE, "rsf_pool_allreduce_sum_all: cannot select device %d", ctxs[i]->device);
+    if ((rc = stage_in(ctxs[i], 0, bufs[i], bytes, &ds[i]))) return rc;
+  }
+  RCCL_TRY(R, R->group_start());
+  for (int32_t i = 0; i < n; ++i) {
+    DeviceGuard guard(ctxs[i]->device);
+    const ncclResult_t e = R->all_reduce(ds[i], (void *)ds[i], (size_t)count, ncclFloat64, ncclSum, ctxs[i]->comm, ctxs[i]->stream);
+    if (e != ncclSuccess) { (void)R->group_end(); return fail(RSF_ERR_DEVICE, "ncclAllReduce (rank %d) -> %s", i, R->error_string(e)); }
+  }
+  RCCL_TRY(R, R->group_end());
+  for (int32_t i = 0; i < n; ++i) {
+    DeviceGuard guard(ctxs[i]->device);
+    if (host_mem(ctxs[i])) HIP_TRY(hipMemcpyAsync(bufs[i], ds[i], bytes, hipMemcpyDeviceToHost, ctxs[i]->stream));
+    if ((rc = finish(ctxs[i]))) return rc;
+  }
+  return RSF_OK;
 }
 
 int rsf_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {

@@ -1,0 +1,692 @@
+// rsf_kernels.h — the gfx950 kernels of the hot path (included by rsf_hip.hip, and by tools/ that build one kernel alone).
+//
+// One lane = one chain, wave64 = 64 independent chains, fp64 VALU bound; no MFMA — the path is an elementwise ODE
+// recurrence plus per-lane reductions, not a contraction:
+//   forward_kernel  K1  batched RateStateModel.evaluate + SSq        (RateStateModel.py:188-395, MCMC.py:381-387)
+//   init_kernel     K4  compute_initial_covariance + initial SSq     (MCMC.py:244-266, 468)
+//   mcmc_kernel     K2  n_iters fused Metropolis iterations          (MCMC.py:494-527)
+//   pool_*          posterior post-processing of the pooled draws    (RSF.py:717-746)
+//   probe_*         K3  Philox / variate self-test entry points
+// The chain-independent tables (loading velocity V_l at the RK4 stage times, observation) are staged through LDS once per
+// workgroup (or per chunk when they exceed the LDS budget) and read as wave-wide broadcasts; per-chain state lives in
+// registers for the whole launch and touches HBM only at launch start/end plus one coalesced trace row per iteration.
+//
+// Per-chain state in HBM is STRUCTURE OF ARRAYS — q[p][C], V[e][C], window sums likewise — so that lane i of a wave reads
+// element i of a contiguous 512-byte run whatever the number of parameters (the C ABI's [C][d] layout is transposed at
+// rsf_mcmc_init / get_state / set_state, rsf_hip.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/rsf_abi.h"
+#include "rsf_device.h"
+#include "rsf_device_dop853.h"
+#include "rsf_device_f32.h"
+
+namespace rsfk {
+
+using rsf::Consts;
+
+enum Mode : int { RK4_F64 = 0, RK4_F32 = 1, DOP853 = 2 };  // how the ODE is integrated (rsf_model.flags)
+
+constexpr int kMaxBlock = 256;  // 4 waves: one per SIMD of a CU
+// Register budget of the sampler kernels: at least this many workgroups per CU, i.e. waves per SIMD (2 => at most 256 of
+// the 512 unified registers per lane).  cfg2 runs 4 waves per SIMD worth of chains, so a kernel that drifts above 256
+// registers would run it in four rounds instead of two; the DOP853 sampler is held to the same budget (unbounded it took
+// 300 registers and ran one wave per SIMD whatever the chain count: profiles/r02/dop853_occupancy_ab.log).
+constexpr int kMinBlocks = 2;
+// three-parameter sampler: TIGHT loop trips of kD3Trip * kTightUnroll steps like the one-parameter sampler's 2 * (+2.3 %
+// over 1 at 131 072 chains x nsteps 4000; the few spills it costs all lie outside the loops)
+constexpr int kD3Trip = 2;
+// LDS per workgroup for the loading table + observation chunk.  Two workgroups per CU (kMinBlocks) at 64 KiB each fit the
+// CU's 160 KiB next to the three-parameter sampler's 12 KiB of Cholesky factors; nsteps 2000 (48 KB) then stays resident
+// for the whole launch instead of being staged twice per proposal (+1.3 % at cfg2).
+constexpr size_t kLdsBudget = 64 * 1024;
+
+// ---------------------------------------------------------------------------------------------
+// kernels
+// ---------------------------------------------------------------------------------------------
+template <bool DAMP, bool WANT_SSQ, bool WANT_ACC, int MODE>
+__global__ void __launch_bounds__(kMaxBlock)
+forward_kernel(Consts K, int64_t n, const double *__restrict__ dc, const double *__restrict__ a,
+               const double *__restrict__ b, double *__restrict__ ssq_out, double *__restrict__ acc_out) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool active = i < n;
+  const double dci = active ? dc[i] : 1.0;
+  const double ai = (active && a) ? a[i] : K.a_def;
+  const double bi = (active && b) ? b[i] : K.b_def;
+  double *acc_i = WANT_ACC ? acc_out + i : nullptr;
+  const bool resident = K.nchunks == 1;
+  double ssq;
+  if constexpr (MODE == RK4_F32) {
+    float *lds32 = reinterpret_cast<float *>(lds);
+    if (resident) rsf::f32::stage_chunk32(lds32, K, 1, K.nout - 1);
+    ssq = rsf::f32::solve32<DAMP, WANT_SSQ, WANT_ACC>(lds32, K, resident, active, dci, ai, bi, acc_i, n);
+  } else {
+    if constexpr (MODE == DOP853) {
+      if (resident) rsf::dp::stage_chunk_dp(lds, K, 1, K.nout - 1);
+      ssq = rsf::dp::solve<DAMP, WANT_SSQ, WANT_ACC>(lds, K, resident, active, dci, ai, bi, acc_i, n);
+    } else {
+      if (resident) rsf::stage_chunk(lds, K, 1, K.nout - 1);
+      ssq = rsf::solve<DAMP, WANT_SSQ, WANT_ACC, 2 * rsf::kTightUnroll>(lds, K, resident, active, dci, ai, bi, acc_i, n);
+    }
+  }
+  if (WANT_SSQ && active) ssq_out[i] = ssq;
+}
+
+struct InitArgs {
+  int64_t C;
+  double fd;       // forward-difference relative step, MCMC.py:251
+  double inv_dof;  // 1 / (nout - len(qpriors)), MCMC.py:261
+  const double *q0;  // [d][C]
+  double *ssq, *std2, *V;  // [C], [C], [d*d][C]
+};
+
+// One trip of NU steps for the unperturbed trajectory and its D perturbed companions, each with its own lane constants
+template <int D, bool DAMP, int T, int NU>
+__device__ __forceinline__ bool lockstep_trip(const double *v, const rsf::Lane (&L)[D + 1], const Consts &K, rsf::State (&st)[D + 1],
+                                              double (&dv)[D + 1][NU]) {
+  bool bad = false;
+#pragma unroll
+  for (int t = 0; t <= D; ++t) {
+    rsf::Lane Lt = L[t];
+    rsf::set_tier<T>(Lt);
+    bad |= rsf::trip_fast<DAMP, T, NU>(v, Lt, K, st[t], dv[t]);
+  }
+  return bad;
+}
+
+// Per chain: the unperturbed solve and one perturbed solve per parameter advance in lockstep, trip by trip, through the
+// same straight-line tier code as the sampler's hot loop (rsf::trip_fast; a tripped guard redoes the trip for all of them
+// with full evaluations and moves on to the next wider tier), so the sensitivity products X^T X accumulate sample by
+// sample without storing trajectories.  The acceleration sample is cv * (sum of the interval's weighted V-derivative
+// sums), like the sampler's (rsf::emit_incr): the initial SSq is the value the sampler computes
+// for the same point to rounding, and the difference of two trajectories' samples — the forward-difference
+// sensitivity, which a relative step of 1e-6 amplifies a million-fold — does not go through two velocities near V_ref.
+template <int D, bool DAMP>
+__global__ void __launch_bounds__(kMaxBlock) init_kernel(Consts K, InitArgs A) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  constexpr int NU = 4;
+  static_assert(rsf::kResync % NU == 0, "the resync test looks at the first step of a trip");
+  rsf::select_group(K);
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool active = i < A.C;
+  double p0[3] = {1.0, K.a_def, K.b_def};
+  if (active) {
+    p0[0] = A.q0[i];
+    if (D == 3) { p0[1] = A.q0[A.C + i]; p0[2] = A.q0[2 * A.C + i]; }
+  }
+  rsf::Lane L[D + 1];
+  rsf::State st[D + 1];
+  double inv_den[D], dsum[D + 1];
+  L[0] = rsf::make_lane(p0[0], p0[1], p0[2], K);
+  st[0] = rsf::initial_state(p0[0], L[0], K);
+  dsum[0] = 0.0;
+#pragma unroll
+  for (int p = 0; p < D; ++p) {
+    double pq[3] = {p0[0], p0[1], p0[2]};
+    pq[p] = pq[p] * (1 + A.fd);
+    inv_den[p] = 1.0 / (pq[p] * A.fd);  // perturbed value in the denominator, MCMC.py:264
+    L[p + 1] = rsf::make_lane(pq[0], pq[1], pq[2], K);
+    st[p + 1] = rsf::initial_state(pq[0], L[p + 1], K);
+    dsum[p + 1] = 0.0;
+  }
+  double xtx[D * D];
+#pragma unroll
+  for (int e = 0; e < D * D; ++e) xtx[e] = 0.0;
+  double ssq = 0.0;
+  if (active) { const double d0 = K.data[0]; ssq = d0 * d0; }
+  const double *ld = lds + rsf::lds_data_offset(K);
+  int phase = 0;  // RK4 steps since the last output sample (wave-uniform)
+  for (int k0 = 1; k0 < K.nout; k0 += K.kc) {
+    const int kn = min(K.kc, K.nout - k0);
+    rsf::stage_chunk(lds, K, k0, kn);
+    if (!active) continue;
+    const int nsteps = K.S * kn;
+    int ko = 0;
+    // an output sample is complete: residual, and the sensitivities' outer product (MCMC.py:264-265)
+    auto emit = [&]() {
+      double ak[D + 1];
+#pragma unroll
+      for (int t = 0; t <= D; ++t) ak[t] = dsum[t] * L[t].cv;
+      const double r = __builtin_fma(dsum[0], L[0].cv, -ld[ko]);
+      ssq = __builtin_fma(r, r, ssq);
+      double x[D];
+#pragma unroll
+      for (int p = 0; p < D; ++p) x[p] = (ak[p + 1] - ak[0]) * inv_den[p];
+#pragma unroll
+      for (int p = 0; p < D; ++p)
+#pragma unroll
+        for (int r2 = 0; r2 < D; ++r2) xtx[p * D + r2] = __builtin_fma(x[p], x[r2], xtx[p * D + r2]);
+#pragma unroll
+      for (int t = 0; t <= D; ++t) dsum[t] = 0.0;
+      ++ko;
+    };
+    int tier = rsf::start_tier(L[0], K);  // wave-uniform; the companions differ from L[0] by 1e-6
+    int r = 0;
+    for (; r + NU <= nsteps; r += NU) {
+      const double *v = lds + 2 * r;
+      if ((r & (rsf::kResync - 1)) == 0) {
+#pragma unroll
+        for (int t = 0; t <= D; ++t) rsf::eval_full(st[t].ms, st[t].x, L[t], K, st[t].w, st[t].rx);
+      }
+      rsf::State save[D + 1];
+#pragma unroll
+      for (int t = 0; t <= D; ++t) save[t] = st[t];
+      double dv[D + 1][NU];
+      bool bad;
+      if (tier == rsf::TIGHT) bad = lockstep_trip<D, DAMP, rsf::TIGHT, NU>(v, L, K, st, dv);
+      else if (tier == rsf::NARROW) bad = lockstep_trip<D, DAMP, rsf::NARROW, NU>(v, L, K, st, dv);
+      else bad = lockstep_trip<D, DAMP, rsf::WIDE, NU>(v, L, K, st, dv);
+      if (__builtin_expect(__builtin_amdgcn_ballot_w64(bad) != 0, 0)) {
+        if (bad) {
+#pragma unroll
+          for (int t = 0; t <= D; ++t) {
+            st[t] = save[t];
+            rsf::trip_cold<DAMP, NU>(v, L[t], K, st[t], dv[t]);
+          }
+        }
+        if (tier < rsf::WIDE) ++tier;
+      }
+#pragma unroll
+      for (int j = 0; j < NU; ++j) {
+#pragma unroll
+        for (int t = 0; t <= D; ++t) dsum[t] += dv[t][j];
+        if (++phase == K.S) { phase = 0; emit(); }
+      }
+    }
+    for (; r < nsteps; ++r) {  // fewer than NU steps left in the chunk: one at a time
+      const double *v = lds + 2 * r;
+      bool bad = false;
+      rsf::State save[D + 1];
+      double dv[D + 1][1];
+#pragma unroll
+      for (int t = 0; t <= D; ++t) {
+        if ((r & (rsf::kResync - 1)) == 0) rsf::eval_full(st[t].ms, st[t].x, L[t], K, st[t].w, st[t].rx);
+        save[t] = st[t];
+      }
+      bad = lockstep_trip<D, DAMP, rsf::WIDE, 1>(v, L, K, st, dv);
+      if (__builtin_expect(__builtin_amdgcn_ballot_w64(bad) != 0, 0)) {
+        if (bad) {
+#pragma unroll
+          for (int t = 0; t <= D; ++t) {
+            st[t] = save[t];
+            rsf::trip_cold<DAMP, 1>(v, L[t], K, st[t], dv[t]);
+          }
+        }
+      }
+#pragma unroll
+      for (int t = 0; t <= D; ++t) dsum[t] += dv[t][0];
+      if (++phase == K.S) { phase = 0; emit(); }
+    }
+  }
+  if (active) {
+    const double std2 = ssq * A.inv_dof;
+    double xi[D * D];
+    rsf::sym_inverse<D>(xtx, xi);
+#pragma unroll
+    for (int e = 0; e < D * D; ++e) A.V[e * A.C + i] = std2 * xi[e];  // MCMC.py:266
+    A.std2[i] = std2;
+    A.ssq[i] = ssq;
+  }
+}
+
+// compute_initial_covariance + initial SSq in the reference's DOP853 scheme: the unperturbed and the perturbed
+// trajectories take their dop853 calls interval by interval in one lane (each with its own carried step size).
+template <int D, bool DAMP>
+__global__ void __launch_bounds__(kMaxBlock) init_dp_kernel(Consts K, InitArgs A) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  rsf::select_group(K);
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool active = i < A.C;
+  double p0[3] = {1.0, K.a_def, K.b_def};
+  if (active) {
+    p0[0] = A.q0[i];
+    if (D == 3) { p0[1] = A.q0[A.C + i]; p0[2] = A.q0[2 * A.C + i]; }
+  }
+  rsf::dp::LaneD L[D + 1];
+  double y[D + 1][3], x[D + 1], hc[D + 1], vprev[D + 1], inv_den[D];
+  bool failed[D + 1], have_kf[D + 1];
+  double kfs[D + 1][3];
+  rsf::dp::Base bfs[D + 1];
+#pragma unroll
+  for (int t = 0; t <= D; ++t) {
+    double pq[3] = {p0[0], p0[1], p0[2]};
+    if (t > 0) {
+      pq[t - 1] = pq[t - 1] * (1 + A.fd);
+      inv_den[t - 1] = 1.0 / (pq[t - 1] * A.fd);  // perturbed value in the denominator, MCMC.py:264
+    }
+    L[t].inv_dc = 1.0 / pq[0]; L[t].kprime = (1e-2 * 10) / pq[0]; L[t].inv_a = 1.0 / pq[1]; L[t].b = pq[2];
+    y[t][0] = K.mu0; y[t][1] = pq[0] / K.V_ref; y[t][2] = K.V_ref;
+    x[t] = K.t0; hc[t] = 0.0; vprev[t] = K.V_ref; failed[t] = false; have_kf[t] = false;
+  }
+  double xtx[D * D];
+#pragma unroll
+  for (int e = 0; e < D * D; ++e) xtx[e] = 0.0;
+  double ssq = 0.0;
+  if (active) { const double d0 = K.data[0]; ssq = d0 * d0; }
+  const double *ld = lds + rsf::dp::lds_data_offset_dp(K);
+  const double delta_t = K.dt;
+  for (int k0 = 1; k0 < K.nout; k0 += K.kc) {
+    const int kn = min(K.kc, K.nout - k0);
+    rsf::dp::stage_chunk_dp(lds, K, k0, kn);
+    if (!active) continue;
+    for (int kk = 0; kk < kn; ++kk) {
+      double ak[D + 1];
+#pragma unroll
+      for (int t = 0; t <= D; ++t) {
+        ak[t] = 0.0;
+        if (!failed[t]) {
+          failed[t] = !rsf::dp::call<DAMP>(K, L[t], lds + rsf::dp::kTab * kk, x[t], x[t] + delta_t, y[t], hc[t], kfs[t], bfs[t], have_kf[t]);
+          ak[t] = (y[t][2] - vprev[t]) * K.inv_dt;
+          vprev[t] = y[t][2];
+        }
+      }
+      const double r = ak[0] - ld[kk];
+      ssq += r * r;
+      double xs[D];
+#pragma unroll
+      for (int p = 0; p < D; ++p) xs[p] = (ak[p + 1] - ak[0]) * inv_den[p];
+#pragma unroll
+      for (int p = 0; p < D; ++p)
+#pragma unroll
+        for (int r2 = 0; r2 < D; ++r2) xtx[p * D + r2] += xs[p] * xs[r2];
+    }
+  }
+  if (active) {
+    const double std2 = ssq * A.inv_dof;
+    double xi[D * D];
+    rsf::sym_inverse<D>(xtx, xi);
+#pragma unroll
+    for (int e = 0; e < D * D; ++e) A.V[e * A.C + i] = std2 * xi[e];  // MCMC.py:266
+    A.std2[i] = std2;
+    A.ssq[i] = ssq;
+  }
+}
+
+// float32 mode: the sampler compares sums of squares from float32 solves, so the initial SSq (computed by the
+// float64 init kernel together with the float64-only sensitivities) is replaced by its float32 value.
+template <int D, bool DAMP>
+__global__ void __launch_bounds__(kMaxBlock) ssq32_kernel(Consts K, int64_t C, const double *q, double *ssq) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  rsf::select_group(K);
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool active = i < C;
+  const double dc = active ? q[i] : 1.0;
+  const double a = (active && D == 3) ? q[C + i] : K.a_def, b = (active && D == 3) ? q[2 * C + i] : K.b_def;
+  const double s = rsf::f32::solve32<DAMP, true, false>(reinterpret_cast<float *>(lds), K, false, active, dc, a, b, nullptr, 0);
+  if (active) ssq[i] = s;
+}
+
+struct McmcArgs {
+  int64_t C, chain_offset, n_iters, iter_base;
+  uint64_t seed;
+  double n0, shape;
+  double gd, gc;  // Marsaglia-Tsang constants of Gamma(shape): d = shape - 1/3, c = 1/sqrt(9 d)
+  double lo[RSF_MAX_PARAMS], hi[RSF_MAX_PARAMS];
+  int32_t adapt_mode, adapt_interval;
+  int32_t lc_off;     // D = 3: offset (in doubles) of the per-lane Cholesky factors behind the table chunk in LDS
+  double dict_scale;  // 2.38^2 / len(qpriors.keys()), MCMC.py:200 (reference_dict mode)
+  double *q, *ssq, *std2, *V;           // per-chain state: q[d][C], ssq[C], std2[C], V[d*d][C]
+  double *wref, *wsum, *wsq;            // adaptation window (shifted sums): [d][C], [d][C], [d*d][C]
+  int32_t *wn;
+  unsigned long long *stats;            // [3] accepted, evaluated, non-finite
+  const double *z, *u, *g;              // replay variates (REPLAY only): z[n][C][d], u[n][C], g[n][C]
+  double *tq, *ts;                      // traces, iteration-major: tq[n][C][d] (the ABI's layout), ts[n][C]
+  uint8_t *ta;
+};
+
+template <int D, bool DAMP, bool REPLAY, int MODE>
+__global__ void __launch_bounds__(kMaxBlock, kMinBlocks) mcmc_kernel(Consts K, McmcArgs A) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  rsf::select_group(K);
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool valid = i < A.C;
+  const uint64_t gid = (uint64_t)(A.chain_offset + i);  // RNG is keyed by the GLOBAL chain id
+  const bool resident = K.nchunks == 1;
+
+  double q[D];
+  double ssq = 0.0, std2 = 1.0;
+#pragma unroll
+  for (int p = 0; p < D; ++p) q[p] = 1.0;
+  // What a proposal needs of the covariance V is its lower Cholesky factor (MCMC.py:497).  D = 1: one double, sqrt(V), kept
+  // in a register with the three doubles of the adaptation window.  D = 3: the factor's six doubles live in LDS, one slot
+  // per lane behind the table chunk (lc[e][lane]: conflict-free), formed from V once per launch and again when the chain
+  // adapts; the window (3 + 3 + 9 doubles of shifted sums) stays in its HBM arrays and is read-modified-written once per
+  // proposal when the chain adapts at all — registers across the forward solve belong to the integrator.
+  constexpr bool kWinRegs = D == 1;
+  double *lcs = lds + A.lc_off + threadIdx.x;  // D = 3: element e of this lane's factor at lcs[e * blockDim.x]
+  double V1 = 0.0;                             // D = 1: the proposal variance
+  double wr[D], ws[D], wq[D * D];
+  int32_t wn = 0;
+  auto store_factor = [&](const double *Lf) {  // row-major lower triangle
+    int e = 0;
+#pragma unroll
+    for (int p = 0; p < D; ++p)
+#pragma unroll
+      for (int r = 0; r <= p; ++r) lcs[(e++) * blockDim.x] = Lf[p * D + r];
+  };
+  if (valid) {
+#pragma unroll
+    for (int p = 0; p < D; ++p) q[p] = A.q[p * A.C + i];
+    ssq = A.ssq[i];
+    std2 = A.std2[i];
+  }
+  if constexpr (D == 1) {
+    if (valid) V1 = A.V[i];
+  } else {
+    double V[D * D], Lf[D * D];
+#pragma unroll
+    for (int e = 0; e < D * D; ++e) V[e] = valid ? A.V[e * A.C + i] : 0.0;
+    rsf::chol_lower<D>(V, Lf);
+    store_factor(Lf);
+  }
+  auto load_window = [&]() {
+#pragma unroll
+    for (int p = 0; p < D; ++p) { wr[p] = A.wref[p * A.C + i]; ws[p] = A.wsum[p * A.C + i]; }
+#pragma unroll
+    for (int e = 0; e < D * D; ++e) wq[e] = A.wsq[e * A.C + i];
+    wn = A.wn[i];
+  };
+  auto store_window = [&]() {
+#pragma unroll
+    for (int p = 0; p < D; ++p) { A.wref[p * A.C + i] = wr[p]; A.wsum[p * A.C + i] = ws[p]; }
+#pragma unroll
+    for (int e = 0; e < D * D; ++e) A.wsq[e * A.C + i] = wq[e];
+    A.wn[i] = wn;
+  };
+  if (kWinRegs && A.adapt_mode != RSF_ADAPT_NONE && valid) load_window();
+  uint32_t n_acc = 0, n_eval = 0, n_nonfinite = 0;
+
+  float *lds32 = reinterpret_cast<float *>(lds);
+  if (resident) {
+    if constexpr (MODE == RK4_F32) rsf::f32::stage_chunk32(lds32, K, 1, K.nout - 1);
+    else if constexpr (MODE == DOP853) rsf::dp::stage_chunk_dp(lds, K, 1, K.nout - 1);
+    else rsf::stage_chunk(lds, K, 1, K.nout - 1);
+  }
+
+  for (int64_t n = 0; n < A.n_iters; ++n) {
+    const uint32_t it = (uint32_t)(A.iter_base + n);
+    const int64_t row = n * A.C + i;
+    // ---- proposal, MCMC.py:497 ----
+    double z[4] = {0.0, 0.0, 0.0, 0.0};
+    if (REPLAY) {
+      if (valid) {
+#pragma unroll
+        for (int p = 0; p < D; ++p) z[p] = A.z[row * D + p];
+      }
+    } else {
+      uint32_t w[4];
+      rsf::draw_words(A.seed, gid, it, rsf::SLOT_Z01, w);
+      rsf::normal_pair(w, z[0], z[1]);
+      if (D > 2) {
+        rsf::draw_words(A.seed, gid, it, rsf::SLOT_Z2, w);
+        rsf::normal_pair(w, z[2], z[3]);
+      }
+    }
+    double qn[D];
+    bool inb = valid;
+    if constexpr (D == 1) {
+      double Lc;
+      rsf::chol_lower<1>(&V1, &Lc);  // sqrt(V), or 0 where V is not positive
+      qn[0] = q[0] + Lc * z[0];
+    } else {
+      int e = 0;
+#pragma unroll
+      for (int p = 0; p < D; ++p) {
+        double s = q[p];
+#pragma unroll
+        for (int r = 0; r <= p; ++r) s += lcs[(e++) * blockDim.x] * z[r];
+        qn[p] = s;
+      }
+    }
+#pragma unroll
+    for (int p = 0; p < D; ++p) inb = inb && (qn[p] > A.lo[p]) && (qn[p] < A.hi[p]);  // strict box, MCMC.py:318-320
+    // ---- likelihood: forward solve only for in-bounds proposals, MCMC.py:322-324 ----
+    double an = K.a_def, bn = K.b_def;
+    if constexpr (D == 3) { an = qn[1]; bn = qn[2]; }
+    double ssqn = 0.0;
+    // (a wave with no in-bounds lane skips the solve when the tables are resident: no barrier inside)
+    if (!resident || __any(inb)) {
+      if constexpr (MODE == RK4_F32) ssqn = rsf::f32::solve32<DAMP, true, false>(lds32, K, resident, inb, qn[0], an, bn, nullptr, 0);
+      else if constexpr (MODE == DOP853) ssqn = rsf::dp::solve<DAMP, true, false>(lds, K, resident, inb, qn[0], an, bn, nullptr, 0);
+      else ssqn = rsf::solve<DAMP, true, false, (D == 1 ? 2 : kD3Trip) * rsf::kTightUnroll>(lds, K, resident, inb, qn[0], an, bn, nullptr, 0);
+    }
+    // ---- accept / reject, MCMC.py:327-333 ----
+    bool accept = false;
+    if (inb) {
+      double u;
+      if (REPLAY) {
+        u = A.u[row];
+      } else {
+        uint32_t w[4];
+        rsf::draw_words(A.seed, gid, it, rsf::SLOT_U, w);
+        u = rsf::u53(w[0], w[1]);
+      }
+      // (replaying recorded variates follows the reference's arithmetic to the last bit: IEEE division, libm-grade log;
+      //  the sampler proper uses the kernel's own reciprocal and log — the same value to ~1 ulp)
+      const double logalpha = fmin(REPLAY ? 0.5 * (ssq - ssqn) / std2 : (0.5 * (ssq - ssqn)) * rsf::fm::rcp(std2), 0.0);
+      accept = logalpha > (REPLAY ? log(u) : rsf::rng_log(u));  // NaN compares false => reject
+      ++n_eval;
+      if (!isfinite(ssqn)) ++n_nonfinite;
+      if (accept) {
+        ssq = ssqn;
+#pragma unroll
+        for (int p = 0; p < D; ++p) q[p] = qn[p];
+        ++n_acc;
+      }
+    }
+    // ---- sigma^2 Gibbs update with the post-accept SSq, MCMC.py:158-160 ----
+    if (valid) {
+      const double bval = 0.5 * (A.n0 * std2 + ssq);
+      const double g = REPLAY ? A.g[row] : rsf::gamma_draw(A.seed, gid, it, A.gd, A.gc);
+      std2 = REPLAY ? bval / g : bval * rsf::fm::rcp(g);
+      if (A.tq) {
+#pragma unroll
+        for (int p = 0; p < D; ++p) A.tq[row * D + p] = q[p];
+      }
+      if (A.ts) A.ts[row] = std2;
+      if (A.ta) A.ta[row] = accept ? 1 : 0;
+    }
+    // ---- adaptation, MCMC.py:200-204, 523-527 ----
+    if (A.adapt_mode != RSF_ADAPT_NONE && valid) {
+      if (!kWinRegs) load_window();
+#pragma unroll
+      for (int p = 0; p < D; ++p) {
+        ws[p] += q[p] - wr[p];
+#pragma unroll
+        for (int r = 0; r < D; ++r) wq[p * D + r] += (q[p] - wr[p]) * (q[r] - wr[r]);
+      }
+      ++wn;
+      if ((A.iter_base + n + 1) % A.adapt_interval == 0) {
+        if (wn >= 2) {
+          const double nn = (double)wn;
+          double Vn[D * D], Ln[D * D];
+          if (A.adapt_mode == RSF_ADAPT_REFERENCE_DICT) {
+            // d := len(qpriors.keys()) (2 for {1: lo, 2: hi}), and the Cholesky FACTOR becomes the next covariance
+            // (one-parameter chains only: rsf_mcmc_init refuses the mode for D = 3)
+            Vn[0] = A.dict_scale * ((wq[0] - ws[0] * ws[0] / nn) / (nn - 1.0));
+            if (rsf::chol_lower<1>(Vn, Ln)) V1 = Ln[0];
+          } else {
+#pragma unroll
+            for (int p = 0; p < D; ++p)
+#pragma unroll
+              for (int r = 0; r < D; ++r)
+                Vn[p * D + r] = 2.38 * 2.38 / (double)D * ((wq[p * D + r] - ws[p] * ws[r] / nn) / (nn - 1.0));
+            if (rsf::chol_lower<D>(Vn, Ln)) {
+              if constexpr (D == 1) {
+                V1 = Vn[0];
+              } else {
+#pragma unroll
+                for (int e = 0; e < D * D; ++e) A.V[e * A.C + i] = Vn[e];
+                store_factor(Ln);
+              }
+            }
+          }
+        }
+        wn = 0;
+#pragma unroll
+        for (int p = 0; p < D; ++p) { wr[p] = q[p]; ws[p] = 0.0; }
+#pragma unroll
+        for (int e = 0; e < D * D; ++e) wq[e] = 0.0;
+      }
+      if (!kWinRegs) store_window();
+    }
+  }
+
+  if (valid) {
+#pragma unroll
+    for (int p = 0; p < D; ++p) A.q[p * A.C + i] = q[p];
+    if constexpr (D == 1) A.V[i] = V1;
+    A.ssq[i] = ssq;
+    A.std2[i] = std2;
+    if (kWinRegs && A.adapt_mode != RSF_ADAPT_NONE) store_window();
+  }
+  // statistics: wave shuffle reduction, one atomic per wave and counter
+  const unsigned long long s0 = rsf::wave_sum(n_acc), s1 = rsf::wave_sum(n_eval), s2 = rsf::wave_sum(n_nonfinite);
+  if ((threadIdx.x & 63) == 0) {
+    if (s0) atomicAdd(&A.stats[0], s0);
+    if (s1) atomicAdd(&A.stats[1], s1);
+    if (s2) atomicAdd(&A.stats[2], s2);
+  }
+}
+
+// [n][d] <-> [d][n] between the C ABI's per-chain layout and the kernels' structure of arrays (d = 3 only; for one
+// parameter the two coincide)
+__global__ void __launch_bounds__(kMaxBlock) transpose_kernel(int64_t n, int d, const double *__restrict__ src, double *__restrict__ dst, bool to_soa) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  for (int e = 0; e < d; ++e) {
+    if (to_soa) dst[(int64_t)e * n + i] = src[i * d + e];
+    else dst[i * d + e] = src[(int64_t)e * n + i];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// posterior post-processing on pooled samples (RSF.plot_dist, RSF.py:717-746)
+// ---------------------------------------------------------------------------------------------
+constexpr int kPoolBlocks = 1024;  // 4 workgroups per CU; partials are combined deterministically (no atomics)
+
+struct PoolPartial {
+  double cnt, sum, sumsq, mn, mx;  // sums are taken about a common shift for stability
+};
+
+__global__ void __launch_bounds__(kMaxBlock)
+pool_moments_kernel(int64_t n, const double *__restrict__ x, int64_t stride, double shift, PoolPartial *__restrict__ part) {
+  __shared__ PoolPartial sh[kMaxBlock / 64];
+  double cnt = 0.0, sum = 0.0, sumsq = 0.0, mn = INFINITY, mx = -INFINITY;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const double v = x[i * stride], dlt = v - shift;
+    cnt += 1.0; sum += dlt; sumsq = __builtin_fma(dlt, dlt, sumsq);
+    mn = fmin(mn, v); mx = fmax(mx, v);
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    cnt += __shfl_down(cnt, off, 64); sum += __shfl_down(sum, off, 64); sumsq += __shfl_down(sumsq, off, 64);
+    mn = fmin(mn, __shfl_down(mn, off, 64)); mx = fmax(mx, __shfl_down(mx, off, 64));
+  }
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = {cnt, sum, sumsq, mn, mx};
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    PoolPartial p = sh[0];
+    for (unsigned w = 1; w < blockDim.x / 64; ++w) {
+      p.cnt += sh[w].cnt; p.sum += sh[w].sum; p.sumsq += sh[w].sumsq; p.mn = fmin(p.mn, sh[w].mn); p.mx = fmax(p.mx, sh[w].mx);
+    }
+    part[blockIdx.x] = p;
+  }
+}
+
+// Fixed-bin histogram (rsf_pool_histogram): HBM-bound, one pass.  Every workgroup counts into an LDS copy of the bins
+// (ds_add_u32), then adds its non-empty bins to the global 64-bit counters — integer atomics, so the result does not
+// depend on the order of arrival.  Bin index = floor((x - lo) * scale), scale = nbins/(hi - lo) from the host: one
+// subtraction and one product, no contraction possible, hence bit-identical to the CPU restatement.
+constexpr int kHistMaxBins = 4096;
+
+__device__ __forceinline__ int hist_bin(double v, double lo, double hi, double scale, int nbins) {
+  if (v < lo) return 0;
+  if (!(v <= hi)) return nbins + 1;                      // above hi, or NaN
+  const int b = (int)floor((v - lo) * scale);
+  return 1 + (b < nbins ? b : nbins - 1);                // v == hi (or rounding at the upper edge) -> last bin
+}
+
+__global__ void __launch_bounds__(kMaxBlock)
+pool_hist_kernel(int64_t n, const double *__restrict__ x, int64_t stride, int nbins, double lo, double hi, double scale,
+                 unsigned long long *__restrict__ counts) {
+  extern __shared__ unsigned int hbins[];
+  for (int b = threadIdx.x; b < nbins + 2; b += blockDim.x) hbins[b] = 0u;
+  __syncthreads();
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    atomicAdd(&hbins[hist_bin(x[i * stride], lo, hi, scale, nbins)], 1u);
+  __syncthreads();
+  for (int b = threadIdx.x; b < nbins + 2; b += blockDim.x)
+    if (hbins[b]) atomicAdd(&counts[b], (unsigned long long)hbins[b]);
+}
+
+__global__ void __launch_bounds__(kMaxBlock) pool_hist_finish_kernel(int nb, const unsigned long long *__restrict__ counts, double *__restrict__ out) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b < nb) out[b] = (double)counts[b];
+}
+
+// Each workgroup owns a contiguous slice of the samples, streamed through LDS in tiles; every thread
+// accumulates the kernel sum of its grid points over the slice (LDS broadcast reads).  partial[block][m].
+constexpr int kKdeTile = 1024;
+
+__global__ void __launch_bounds__(kMaxBlock)
+pool_kde_kernel(int64_t n, const double *__restrict__ x, int64_t stride, int m, const double *__restrict__ grid, double inv2c,
+                double *__restrict__ partial) {
+  __shared__ double tile[kKdeTile];
+  const int64_t per = (n + gridDim.x - 1) / gridDim.x, lo = (int64_t)blockIdx.x * per, hi = min(n, lo + per);
+  for (int j0 = 0; j0 < m; j0 += blockDim.x) {
+    const int j = j0 + threadIdx.x;
+    const double g = j < m ? grid[j] : 0.0;
+    double acc = 0.0;
+    for (int64_t t0 = lo; t0 < hi; t0 += kKdeTile) {
+      const int tn = (int)min((int64_t)kKdeTile, hi - t0);
+      __syncthreads();
+      for (int t = threadIdx.x; t < tn; t += blockDim.x) tile[t] = x[(t0 + t) * stride];
+      __syncthreads();
+      for (int t = 0; t < tn; ++t) {
+        const double dlt = g - tile[t];
+        acc += rsf::fm::exp(-dlt * dlt * inv2c);
+      }
+    }
+    if (j < m) partial[(int64_t)blockIdx.x * m + j] = acc;
+  }
+}
+
+__global__ void __launch_bounds__(kMaxBlock)
+pool_kde_reduce_kernel(int nblocks, int m, const double *__restrict__ partial, double norm, double *__restrict__ density) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= m) return;
+  double acc = 0.0;
+  for (int b = 0; b < nblocks; ++b) acc += partial[(int64_t)b * m + j];  // fixed order: reproducible
+  density[j] = acc * norm;
+}
+
+// out[0..3] = philox words (as doubles are not used here): layout documented at the call sites
+__global__ void probe_philox_kernel(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
+                                    uint32_t *out) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    uint32_t w[4];
+    rsf::philox4x32_10(c0, c1, c2, c3, k0, k1, w);
+    for (int j = 0; j < 4; ++j) out[j] = w[j];
+  }
+}
+
+// out = { z0, z1, z2, u, g }
+__global__ void probe_draws_kernel(uint64_t seed, uint64_t chain, uint32_t iter, int d, double shape, double *out) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    uint32_t w[4];
+    double z[4] = {0, 0, 0, 0};
+    rsf::draw_words(seed, chain, iter, rsf::SLOT_Z01, w);
+    rsf::normal_pair(w, z[0], z[1]);
+    if (d > 2) { rsf::draw_words(seed, chain, iter, rsf::SLOT_Z2, w); rsf::normal_pair(w, z[2], z[3]); }
+    rsf::draw_words(seed, chain, iter, rsf::SLOT_U, w);
+    out[0] = z[0]; out[1] = z[1]; out[2] = z[2];
+    out[3] = rsf::u53(w[0], w[1]);
+    out[4] = rsf::gamma_draw(seed, chain, iter, shape - 1.0 / 3.0, 1.0 / sqrt(9.0 * (shape - 1.0 / 3.0)));
+  }
+}
+
+}  // namespace rsfk

@@ -19,27 +19,14 @@ namespace fm {
 
 // Horner step p*x + c of the hot-loop series.  Plain fma: with the full log/exp out of the hot loop its
 // nine coefficients stay in SGPRs and hipcc emits one 3-address v_fma_f64 v, v, v, s[..] per term.
-// (Earlier, with ~35 live constants, it fell back to v_mov_b64 + 2-address v_fmac_f64 per term; the
-// explicit-asm form below fixed that but costs an s_nop after each asm statement, so it is now only an
-// A/B switch: -DRSF_ASM_FMA.)
-__device__ __forceinline__ double hfma(double p, double x, double c) {
-#ifndef RSF_ASM_FMA
-  return __builtin_fma(p, x, c);
-#else
-  double r;
-  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(p), "v"(x), "s"(c));
-  return r;
-#endif
-}
+__device__ __forceinline__ double hfma(double p, double x, double c) { return __builtin_fma(p, x, c); }
 
-#ifndef RSF_RCP_NR_STEPS
-#define RSF_RCP_NR_STEPS 2
-#endif
+constexpr int kRcpNewtonSteps = 2;  // after the v_rcp_f64 seed (measured 4.6e-8): 2e-15, then < 1 ulp
 
 __device__ __forceinline__ double rcp(double x) {
   double r = __builtin_amdgcn_rcp(x);  // v_rcp_f64: hardware seed
 #pragma unroll
-  for (int i = 0; i < RSF_RCP_NR_STEPS; ++i) {
+  for (int i = 0; i < kRcpNewtonSteps; ++i) {
     const double e = __builtin_fma(-x, r, 1.0);
     r = __builtin_fma(r, e, r);
   }

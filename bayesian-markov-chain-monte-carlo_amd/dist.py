@@ -110,7 +110,45 @@ def allreduce_histogram(counts, group=None, device=None):
 def pool_to_chain_major(pool):
     """(G, n_keep, C_local, d) → (n_keep, G*C_local, d): global chain id = g*C_local + c."""
     G, n, C, d = pool.shape
+    if isinstance(pool, np.ndarray):
+        return np.ascontiguousarray(pool.transpose(1, 0, 2, 3)).reshape(n, G * C, d)
     return pool.permute(1, 0, 2, 3).reshape(n, G * C, d)
+
+
+def run_single_process(engines, model, substeps, data, q0_global, lo, hi, n_iters, nburn, seed=0, mcmc_kwargs=None, thin=1):
+    """SURVEY §8e's process model without a launcher: ONE host thread drives `engines` (one per GPU, typically
+    `[Engine(mem="device", device=g) for g in range(n)]`).  Engine r samples the contiguous block r of global chain ids
+    — device-memory engines only enqueue, so all GPUs compute at once — then the kept draws are pooled with one grouped
+    RCCL all-gather through the C ABI (rsf_comm_init_all + rsf_pool_allgather_all).  The reference runs the same chains
+    one after another (RSF.py:1042-1044).  Returns (pools, stats): pools[r] is the (n_keep, C, d) pool as engine r
+    holds it (identical on every rank), stats[r] engine r's counters."""
+    if __package__:
+        from .engine import Engine
+    else:
+        from engine import Engine
+    G = len(engines)
+    q0_global = np.asarray(q0_global, dtype=np.float64)
+    q0_global = q0_global.reshape(q0_global.shape[0], -1)
+    kept = []
+    for r, eng in enumerate(engines):
+        off, per = shard_bounds(q0_global.shape[0], G, r)
+        eng.set_model(model, substeps)
+        eng.mcmc_init(q0_global[off:off + per], data, lo, hi, seed=seed, chain_offset=off, **(mcmc_kwargs or {}))
+    for eng in engines:  # (a second loop: every init has been synchronous, the runs overlap across GPUs)
+        tq, _, _ = eng.mcmc_run(n_iters, traces=("q",))
+        kept.append(tq[max(nburn - 1, 0):][::thin])
+    for eng in engines:
+        eng.sync()
+    made = not engines[0].world
+    if made:
+        Engine.comm_init_all(engines)
+    try:
+        pools = [pool_to_chain_major(p) for p in Engine.pool_allgather_all(engines, kept)]
+    finally:
+        if made:
+            for eng in engines:
+                eng.comm_destroy()
+    return pools, [eng.stats() for eng in engines]
 
 
 def run_sharded(engine_factory, model, substeps, data, q0_global, lo, hi, n_iters, nburn, seed=0, mcmc_kwargs=None,

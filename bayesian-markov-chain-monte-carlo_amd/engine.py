@@ -66,6 +66,7 @@ class Engine:
                                     "csrc/librsf_hip.so only (no CPU fallback); checkers set RSF_ALLOW_CHECKER_ENGINE=1")
         self.lib = lib
         self.mem = mem
+        self.device = device
         self._torch = None
         cfg = _abi.Config()
         cfg.size, cfg.version = ctypes.sizeof(_abi.Config), _abi.ABI_VERSION
@@ -76,10 +77,11 @@ class Engine:
             import torch
 
             self._torch = torch
-            if device >= 0:
-                torch.cuda.set_device(device)
+            if device < 0:
+                device = torch.cuda.current_device()
+            self.device = cfg.device = device  # buffers and launches of this engine stay on this GPU whatever is current
             if stream is None:
-                stream = torch.cuda.current_stream().cuda_stream
+                stream = torch.cuda.current_stream(device).cuda_stream
         cfg.stream = stream
         self._ctx = ctypes.c_void_p()
         _abi.check(lib, lib.rsf_create(ctypes.byref(cfg), ctypes.byref(self._ctx)))
@@ -108,7 +110,7 @@ class Engine:
     def _empty(self, shape, dtype=np.float64):
         if self.mem == "device":
             t = self._torch
-            return t.empty(shape, dtype=t.uint8 if dtype == np.uint8 else t.float64, device="cuda")
+            return t.empty(shape, dtype=t.uint8 if dtype == np.uint8 else t.float64, device=f"cuda:{self.device}")
         return np.empty(shape, dtype=dtype)
 
     def _in(self, x, dtype=np.float64):
@@ -119,7 +121,7 @@ class Engine:
             t = self._torch
             if not isinstance(x, t.Tensor):
                 x = t.as_tensor(np.ascontiguousarray(x, dtype=dtype))
-            return x.to(device="cuda", dtype=t.float64).contiguous()
+            return x.to(device=f"cuda:{self.device}", dtype=t.float64).contiguous()
         return np.ascontiguousarray(x, dtype=dtype)
 
     @staticmethod
@@ -301,6 +303,51 @@ class Engine:
         x = self._in(buf)
         _abi.check(self.lib, self.lib.rsf_pool_allreduce_sum(self._ctx, self._ptr(x), int(np.prod(x.shape))))
         return x
+
+    # -- the same exchange driven by ONE host thread that owns several engines (one per GPU): SURVEY §8e's process model --
+    @staticmethod
+    def _ctx_array(engines):
+        if not engines:
+            raise ValueError("need at least one engine")
+        lib = engines[0].lib
+        if any(e.lib is not lib for e in engines):
+            raise ValueError("all engines of a group must come from the same library")
+        return lib, (ctypes.c_void_p * len(engines))(*[e._ctx for e in engines])
+
+    @staticmethod
+    def comm_init_all(engines):
+        """rsf_comm_init_all: engines[i] becomes rank i of a len(engines)-rank group (ncclCommInitAll; no id, no launcher)."""
+        lib, ctxs = Engine._ctx_array(engines)
+        _abi.check(lib, lib.rsf_comm_init_all(ctxs, len(engines)))
+        for r, e in enumerate(engines):
+            e.world, e.rank = len(engines), r
+
+    @staticmethod
+    def pool_allgather_all(engines, locals_):
+        """One grouped all-gather: locals_[r] (same shape on every rank, in engines[r]'s memory space) → list of
+        (world,) + shape arrays, one per engine, each holding every rank's block."""
+        lib, ctxs = Engine._ctx_array(engines)
+        n = len(engines)
+        xs = [e._in(x) for e, x in zip(engines, locals_)]
+        if len(xs) != n or any(tuple(x.shape) != tuple(xs[0].shape) for x in xs):
+            raise ValueError("one block of the same shape per engine")
+        outs = [e._empty((n,) + tuple(xs[0].shape)) for e in engines]
+        send = (ctypes.c_void_p * n)(*[Engine._ptr(x) for x in xs])
+        recv = (ctypes.c_void_p * n)(*[Engine._ptr(o) for o in outs])
+        _abi.check(lib, lib.rsf_pool_allgather_all(ctxs, n, send, int(np.prod(xs[0].shape)), recv))
+        return outs
+
+    @staticmethod
+    def pool_allreduce_sum_all(engines, bufs):
+        """One grouped in-place sum over ranks: bufs[r] lives in engines[r]'s memory space → the summed buffers."""
+        lib, ctxs = Engine._ctx_array(engines)
+        n = len(engines)
+        xs = [e._in(x) for e, x in zip(engines, bufs)]
+        if len(xs) != n or any(tuple(x.shape) != tuple(xs[0].shape) for x in xs):
+            raise ValueError("one buffer of the same shape per engine")
+        ptrs = (ctypes.c_void_p * n)(*[Engine._ptr(x) for x in xs])
+        _abi.check(lib, lib.rsf_pool_allreduce_sum_all(ctxs, n, ptrs, int(np.prod(xs[0].shape))))
+        return xs
 
     # -- RNG helpers (tests) --------------------------------------------------------------
     def philox(self, ctr, key):

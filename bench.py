@@ -289,6 +289,10 @@ def main():
     ap.add_argument("--integrator", default="rk4", choices=["rk4", "dop853"],
                     help="dop853 = the reference's own adaptive scheme (side measurement / profiling; the metric is quoted on rk4)")
     ap.add_argument("--precision", default="float64", choices=["float64", "float32"], help="float32 = config-5 tolerance-sweep solve")
+    ap.add_argument("--abi-pool", action="store_true",
+                    help="N > 1: repeat the pool exchange through the C ABI's own RCCL communicator after the timed region (rsf_comm_init + "
+                         "rsf_pool_allgather, under a watchdog; a hang there ends the run with status 3) — opt-in, so that the driver's "
+                         "scaling run depends only on the torch.distributed exchange")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend for N > 1 (nccl = RCCL; gloo only to rehearse the N > 1 path on one GPU)")
     args = ap.parse_args()
@@ -348,7 +352,7 @@ def main():
         torch.cuda.synchronize()
         allgather_ms = (time.perf_counter() - g0) * 1e3
         assert pool.shape == (ips, world * C, d)
-        abi_pool = abi_pool_allgather(eng, traces[0], pool, rdist) if args.backend == "nccl" else None
+        abi_pool = abi_pool_allgather(eng, traces[0], pool, rdist) if (args.abi_pool and args.backend == "nccl") else None
     else:
         allgather_ms = abi_pool = None
 

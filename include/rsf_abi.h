@@ -227,13 +227,28 @@ int rsf_pool_histogram(rsf_ctx *ctx, int64_t n, const double *x, int64_t stride,
  * Buffers are in the ctx memory space like everywhere else; the collectives run on the ctx stream.
  * RCCL is bound at run time (the copy already in the process — e.g. PyTorch's — else librccl.so.1;
  * RSF_RCCL_LIB overrides).  world = 1 with id = NULL needs no RCCL (copies); with an id it is a real one-rank
- * communicator.  The CPU oracle supports world = 1 only. */
+ * communicator.  The CPU oracle supports world > 1 only with RSF_RCCL_LIB naming a host-memory implementation of the
+ * nccl* entry points (the test-suite's tests/c/fake_rccl.c). */
 #define RSF_COMM_ID_BYTES 128
 int rsf_comm_unique_id(uint8_t id[RSF_COMM_ID_BYTES]);
 int rsf_comm_init(rsf_ctx *ctx, int32_t world, int32_t rank, const uint8_t id[RSF_COMM_ID_BYTES]);
 int rsf_comm_destroy(rsf_ctx *ctx);
 int rsf_pool_allgather(rsf_ctx *ctx, const double *send, int64_t count, double *recv);
 int rsf_pool_allreduce_sum(rsf_ctx *ctx, double *buf, int64_t count);
+
+/* The same exchange for a SINGLE process that owns every GPU of the node (SURVEY §8e's process model: "single process,
+ * ncclCommInitAll over visible devices ... ncclGroupStart/End around the all-gather calls") — what a plain C caller, or any
+ * caller without a process launcher, uses: one ctx per device, one host thread.
+ *   rsf_comm_init_all(ctxs, n)       ncclCommInitAll over the ctxs' devices; ctxs[i] becomes rank i of world n.  Not
+ *                                    collective across threads or processes (rsf_comm_init blocks until every rank has
+ *                                    joined, so one thread holding all the ctxs could never finish it).
+ *   rsf_pool_allgather_all(...)      one grouped all-gather: recv[i][r*count .. (r+1)*count) = send[r][0 .. count) for all i, r
+ *   rsf_pool_allreduce_sum_all(...)  one grouped all-reduce: bufs[i][k] = sum over r of bufs[r][k], in place on every ctx
+ * send[i] / recv[i] / bufs[i] live in ctxs[i]'s memory space (device buffers on ctxs[i]'s device); the collectives run on
+ * each ctx's stream; host-space results are complete on return.  rsf_comm_destroy(ctxs[i]) ends each communicator. */
+int rsf_comm_init_all(rsf_ctx *const *ctxs, int32_t n);
+int rsf_pool_allgather_all(rsf_ctx *const *ctxs, int32_t n, const double *const *send, int64_t count, double *const *recv);
+int rsf_pool_allreduce_sum_all(rsf_ctx *const *ctxs, int32_t n, double *const *bufs, int64_t count);
 
 /* The Philox4x32-10 block function itself (known-answer tests; Random123 vectors). */
 int rsf_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);

@@ -29,7 +29,9 @@
 #include "../include/rsf_abi.h"
 #include "../include/rsf_dop853_tableau.h"
 
+#include <dlfcn.h>
 #include <math.h>
+#include <pthread.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -127,7 +129,8 @@ struct rsf_ctx {
   int32_t *wn;                  /* [C] samples in window */
   int64_t iters_done;
   int64_t n_acc, n_eval, n_nonfinite;
-  int32_t world;                /* 0: rsf_comm_init not called; the checker is single-process (world 1) */
+  int32_t world, rank;          /* world 0: rsf_comm_init not called */
+  void *comm;                   /* world > 1: communicator of the nccl implementation named by RSF_RCCL_LIB (tests/c/fake_rccl.c) */
 };
 
 int rsf_version(void) { return RSF_ABI_VERSION; }
@@ -158,6 +161,7 @@ static void free_chains(rsf_ctx *c) {
 
 int rsf_destroy(rsf_ctx *c) {
   if (!c) return RSF_OK;
+  rsf_comm_destroy(c);
   free_chains(c);
   free(c);
   return RSF_OK;
@@ -182,9 +186,8 @@ int rsf_set_model(rsf_ctx *c, const rsf_model *m) {
   if (m->size != sizeof(rsf_model)) return fail(RSF_ERR_INVALID, "rsf_set_model: struct size mismatch");
   if (m->nsteps < 2 || m->substeps < 1 || !(m->t_final > m->t_start))
     return fail(RSF_ERR_INVALID, "rsf_set_model: need nsteps >= 2, substeps >= 1, t_final > t_start");
-  if (m->flags & RSF_FLAG_FP32_SOLVE)
-    return fail(RSF_ERR_UNSUPPORTED, "rsf_set_model: the CPU restatement is float64 only (the float32 solve is "
-                                     "checked against the float64 GPU path within the sweep tolerance)");
+  if ((m->flags & RSF_FLAG_FP32_SOLVE) && (m->flags & RSF_FLAG_DOP853))
+    return fail(RSF_ERR_INVALID, "rsf_set_model: the dop853 integrator is float64 only");
   if (c->have_chains) free_chains(c);  /* chain state belongs to the previous model */
   c->m = *m;
   c->delta_t = (m->t_final - m->t_start) / m->nsteps;                   /* RateStateModel.py:176 */
@@ -224,10 +227,76 @@ static void friction(const rsf_model *m, double t, double dc, double a, double b
  * sees bit-identical arguments.  Returns SSq if data != NULL; writes acc[k*stride] if acc. */
 static double solve_dop853(const rsf_ctx *c, double dc, double a, double b, const double *data, double *acc, int64_t stride);
 
+/* RSF_FLAG_FP32_SOLVE (BASELINE config 5's float32 leg): the same fixed-step RK4 carried in IEEE float — plain `float`
+ * arithmetic, exp2f / log2f, one rounding per operation (fmaf where the formula is a fused multiply-add).  It restates
+ * the float32 FORMULATION of the product (csrc/rsf_device_f32.h), not an independent algorithm: the rescaled state
+ * ms = mu/k', x = V_ref theta/Dc, the exponent pre-scaled to base 2, the acceleration sample from the step's velocity
+ * increment (differencing two float velocities near V_ref would lose four digits), float tables, and a double sum of
+ * squares of float residuals.  GPU and this restatement then differ only by the last-place behaviour of the hardware
+ * v_exp_f32 / v_log_f32 / v_rcp_f32 against libm — which pins every constant and every term of the kernel far below
+ * the 1e-3 band that separates float32 from float64 results. */
+typedef struct { float kia2, tc2, boa, kprime, k1k, via, bdc, hh, h, h6, hhd, hd, h6d, vref; } lane32;
+
+static void rhs32(const lane32 *L, int damp, float ms, float x, float vl, float *d0, float *d1, float *d2) {
+  float w = exp2f(fmaf(-L->boa, log2f(x), fmaf(ms, L->kia2, L->tc2)));   /* v/V_ref */
+  float rx = 1.0f / x;
+  float e1 = fmaf(-w, x, 1.0f);                                          /* RateStateModel.py:340 */
+  float e0 = fmaf(-L->vref, w, vl);                                      /* :343, in units of k' */
+  float bt = (L->bdc * e1) * rx;
+  float va = w * L->via;
+  float e2 = va * fmaf(L->kprime, e0, -bt);                              /* :346 */
+  if (damp) {                                                            /* :349-353 */
+    e0 = fmaf(-L->k1k, e2, e0);
+    e2 = va * fmaf(L->kprime, e0, -bt);
+  }
+  *d0 = e0; *d1 = e1; *d2 = e2;
+}
+
+static double solve_f32(const rsf_ctx *c, double dc, double a, double b, const double *data, double *acc, int64_t stride) {
+  const rsf_model *m = &c->m;
+  const int S = m->substeps, damp = (m->flags & RSF_FLAG_RADIATION_DAMPING) != 0;
+  const double h = c->h, hh = 0.5 * c->h, h6 = c->h / 6.0, log2e = 1.4426950408889634074;
+  const double inv_a = 1.0 / a, inv_dc = 1.0 / dc, kprime = (1e-2 * 10) / dc, vdc = m->V_ref * inv_dc;
+  lane32 L;
+  L.kia2 = (float)(kprime * inv_a * log2e); L.tc2 = (float)(-m->mu_ref * inv_a * log2e); L.boa = (float)(b * inv_a);
+  L.kprime = (float)kprime; L.k1k = (float)(m->k1 / kprime); L.via = (float)(m->V_ref * inv_a); L.bdc = (float)(b * m->V_ref * inv_dc);
+  L.hh = (float)hh; L.h = (float)h; L.h6 = (float)h6;
+  L.hhd = (float)(hh * vdc); L.hd = (float)(h * vdc); L.h6d = (float)(h6 * vdc); L.vref = (float)m->V_ref;
+  const float inv_dt = (float)(1.0 / c->delta_t);
+  float ms = (float)(m->mu_t_zero / kprime), x = 1.0f;
+  double ssq = 0.0;
+  int64_t j = 0;
+  if (acc) acc[0] = 0.0;
+  if (data) { double d0 = (double)(float)data[0]; ssq = d0 * d0; }
+  for (int32_t k = 1; k < c->nout; ++k) {
+    float dv = 0.0f;
+    for (int s = 0; s < S; ++s, j += 2) {
+      /* the float loading table of the product: V_l at t_start + j*h/2 evaluated in double, rounded to float */
+      double t0 = m->t_start + (double)j * hh, tm = m->t_start + (double)(j + 1) * hh, t1 = m->t_start + (double)(j + 2) * hh;
+      float vl0 = (float)(m->V_ref * (1 + exp(-t0 / 20) * sin(10 * t0)));
+      float vlm = (float)(m->V_ref * (1 + exp(-tm / 20) * sin(10 * tm)));
+      float vl1 = (float)(m->V_ref * (1 + exp(-t1 / 20) * sin(10 * t1)));
+      float a0, a1, a2, b0, b1, b2, c0, c1, c2, e0, e1, e2;
+      rhs32(&L, damp, ms, x, vl0, &a0, &a1, &a2);
+      rhs32(&L, damp, fmaf(L.hh, a0, ms), fmaf(L.hhd, a1, x), vlm, &b0, &b1, &b2);
+      rhs32(&L, damp, fmaf(L.hh, b0, ms), fmaf(L.hhd, b1, x), vlm, &c0, &c1, &c2);
+      rhs32(&L, damp, fmaf(L.h, c0, ms), fmaf(L.hd, c1, x), vl1, &e0, &e1, &e2);
+      ms = fmaf(L.h6, a0 + 2.0f * b0 + 2.0f * c0 + e0, ms);
+      x = fmaf(L.h6d, a1 + 2.0f * b1 + 2.0f * c1 + e1, x);
+      dv += L.h6 * (a2 + 2.0f * b2 + 2.0f * c2 + e2);
+    }
+    float ak = dv * inv_dt;                                              /* RateStateModel.py:388, from the increment */
+    if (acc) acc[k * stride] = (double)ak;
+    if (data) { double r = (double)(ak - (float)data[k]); ssq = fma(r, r, ssq); }
+  }
+  return ssq;
+}
+
 static double solve(const rsf_ctx *c, double dc, double a, double b, const double *data, double *acc,
                     int64_t stride) {
   const rsf_model *m = &c->m;
   if (m->flags & RSF_FLAG_DOP853) return solve_dop853(c, dc, a, b, data, acc, stride);
+  if (m->flags & RSF_FLAG_FP32_SOLVE) return solve_f32(c, dc, a, b, data, acc, stride);
   const int S = m->substeps;
   const double h = c->h, hh = 0.5 * c->h;
   double y[3] = {m->mu_t_zero, dc / m->V_ref, m->V_ref}; /* RateStateModel.py:367-377 */
@@ -479,6 +548,11 @@ int rsf_mcmc_init(rsf_ctx *c, const rsf_mcmc_config *cfg, const double *q0, cons
   memcpy(c->wref, q0, sizeof(double) * C * d);
   const int plen = cfg->prior_len ? cfg->prior_len : d;
   const double fd = cfg->fd_rel_step;
+  /* float32 mode, like the product: the forward-difference sensitivities (relative step 1e-6) and std2_0 stay float64;
+   * only the initial SSq the sampler will compare against is the float32 solve's */
+  rsf_ctx c64 = *c;
+  c64.m.flags &= ~RSF_FLAG_FP32_SOLVE;
+  const int f32 = (c->m.flags & RSF_FLAG_FP32_SOLVE) != 0;
   int nt = nthreads(c);
   (void)nt;
 #pragma omp parallel num_threads(nt)
@@ -489,13 +563,13 @@ int rsf_mcmc_init(rsf_ctx *c, const rsf_mcmc_config *cfg, const double *q0, cons
     for (int64_t i = 0; i < C; ++i) {
       const double *q = c->q + i * d;
       double a = d == 3 ? q[1] : c->m.a, b = d == 3 ? q[2] : c->m.b;
-      double s0 = solve(c, q[0], a, b, data_of(c, i), acc0, 1);    /* MCMC.py:245-246, 468 */
+      double s0 = solve(&c64, q[0], a, b, data_of(c, i), acc0, 1);    /* MCMC.py:245-246, 468 */
       double qp[3], XtX[9], Xi[9];
       for (int p = 0; p < d; ++p) {                          /* MCMC.py:251-252 */
         double pq[3] = {q[0], a, b};
         pq[p] = pq[p] * (1 + fd);
         qp[p] = pq[p];
-        solve(c, pq[0], pq[1], pq[2], NULL, accp + (int64_t)p * N, 1);
+        solve(&c64, pq[0], pq[1], pq[2], NULL, accp + (int64_t)p * N, 1);
       }
       for (int p = 0; p < d; ++p)
         for (int r = 0; r < d; ++r) {
@@ -511,7 +585,7 @@ int rsf_mcmc_init(rsf_ctx *c, const rsf_mcmc_config *cfg, const double *q0, cons
       sym_inverse(XtX, d, Xi);
       for (int e = 0; e < d * d; ++e) c->V[i * d * d + e] = std2 * Xi[e]; /* MCMC.py:266 */
       c->std2[i] = std2;
-      c->ssq[i] = s0;
+      c->ssq[i] = f32 ? solve(c, q[0], a, b, data_of(c, i), NULL, 0) : s0;
     }
     free(acc0);
     free(accp);
@@ -728,39 +802,162 @@ int rsf_pool_histogram(rsf_ctx *c, int64_t n, const double *x, int64_t stride, i
   return RSF_OK;
 }
 
-/* Pool collectives (include/rsf_abi.h): the checker is one process, so only world = 1 exists here —
- * enough to run the same host code against both libraries. */
+/* Pool collectives (include/rsf_abi.h).  The checker itself is one process on host memory: world = 1 is a copy.  For
+ * world > 1 it binds — exactly like the product, through RSF_RCCL_LIB — an implementation of the nccl* entry points that
+ * works on host pointers (the test-suite's tests/c/fake_rccl.c; the real RCCL needs device memory and is never loaded
+ * here), so that the same multi-rank host code can be run against both libraries. */
+typedef struct { char internal[RSF_COMM_ID_BYTES]; } oracle_uid;
+static struct {
+  void *h;
+  int (*get_unique_id)(oracle_uid *);
+  int (*comm_init_rank)(void **, int, oracle_uid, int);
+  int (*comm_init_all)(void **, int, const int *);
+  int (*comm_destroy)(void *);
+  int (*group_start)(void);
+  int (*group_end)(void);
+  int (*all_gather)(const void *, void *, size_t, int, void *, void *);
+  int (*all_reduce)(const void *, void *, size_t, int, int, void *, void *);
+} g_nccl;
+static pthread_once_t g_nccl_once = PTHREAD_ONCE_INIT;
+enum { NCCL_FLOAT64 = 8, NCCL_SUM = 0 };
+
+static void bind_nccl(void) {
+  const char *path = getenv("RSF_RCCL_LIB");
+  if (!path || !*path) return;
+  void *h = dlopen(path, RTLD_NOW | RTLD_LOCAL);
+  if (!h) return;
+  *(void **)&g_nccl.get_unique_id = dlsym(h, "ncclGetUniqueId");
+  *(void **)&g_nccl.comm_init_rank = dlsym(h, "ncclCommInitRank");
+  *(void **)&g_nccl.comm_init_all = dlsym(h, "ncclCommInitAll");
+  *(void **)&g_nccl.comm_destroy = dlsym(h, "ncclCommDestroy");
+  *(void **)&g_nccl.group_start = dlsym(h, "ncclGroupStart");
+  *(void **)&g_nccl.group_end = dlsym(h, "ncclGroupEnd");
+  *(void **)&g_nccl.all_gather = dlsym(h, "ncclAllGather");
+  *(void **)&g_nccl.all_reduce = dlsym(h, "ncclAllReduce");
+  if (g_nccl.get_unique_id && g_nccl.comm_init_rank && g_nccl.comm_init_all && g_nccl.comm_destroy && g_nccl.group_start &&
+      g_nccl.group_end && g_nccl.all_gather && g_nccl.all_reduce)
+    g_nccl.h = h;
+}
+
+static int have_nccl(void) {
+  pthread_once(&g_nccl_once, bind_nccl);
+  return g_nccl.h != NULL;
+}
+
 int rsf_comm_unique_id(uint8_t id[RSF_COMM_ID_BYTES]) {
   if (!id) return fail(RSF_ERR_INVALID, "rsf_comm_unique_id: NULL argument");
   memset(id, 0, RSF_COMM_ID_BYTES);
+  if (have_nccl()) {
+    oracle_uid u;
+    if (g_nccl.get_unique_id(&u)) return fail(RSF_ERR_DEVICE, "rsf_comm_unique_id: ncclGetUniqueId failed");
+    memcpy(id, u.internal, RSF_COMM_ID_BYTES);
+  }
   return RSF_OK;
 }
 
 int rsf_comm_init(rsf_ctx *c, int32_t world, int32_t rank, const uint8_t id[RSF_COMM_ID_BYTES]) {
-  (void)id;
   if (!c || world < 1 || rank < 0 || rank >= world) return fail(RSF_ERR_INVALID, "rsf_comm_init: bad argument");
   if (c->world) return fail(RSF_ERR_STATE, "rsf_comm_init: this ctx already has a communicator (rsf_comm_destroy first)");
-  if (world > 1) return fail(RSF_ERR_UNSUPPORTED, "rsf_comm_init: the CPU oracle is single-process (world = 1 only)");
-  c->world = 1;
+  if (world > 1) {
+    if (!have_nccl())
+      return fail(RSF_ERR_UNSUPPORTED, "rsf_comm_init: the CPU oracle is single-process (world = 1 only) unless RSF_RCCL_LIB "
+                                       "names a host-memory implementation of the nccl entry points");
+    if (!id) return fail(RSF_ERR_INVALID, "rsf_comm_init: world > 1 needs the id from rsf_comm_unique_id on rank 0");
+    oracle_uid u;
+    memcpy(u.internal, id, RSF_COMM_ID_BYTES);
+    if (g_nccl.comm_init_rank(&c->comm, world, u, rank)) return fail(RSF_ERR_DEVICE, "rsf_comm_init: ncclCommInitRank failed");
+  }
+  c->world = world;
+  c->rank = rank;
   return RSF_OK;
 }
 
 int rsf_comm_destroy(rsf_ctx *c) {
   if (!c) return fail(RSF_ERR_INVALID, "rsf_comm_destroy: NULL ctx");
+  if (c->comm) { g_nccl.comm_destroy(c->comm); c->comm = NULL; }
   c->world = 0;
+  c->rank = 0;
   return RSF_OK;
 }
 
 int rsf_pool_allgather(rsf_ctx *c, const double *send, int64_t count, double *recv) {
   if (!c || !send || !recv || count < 1) return fail(RSF_ERR_INVALID, "rsf_pool_allgather: bad argument");
   if (!c->world) return fail(RSF_ERR_STATE, "rsf_pool_allgather: call rsf_comm_init first");
-  if (recv != send) memmove(recv, send, (size_t)count * sizeof(double));
+  if (c->comm) {
+    if (g_nccl.all_gather(send, recv, (size_t)count, NCCL_FLOAT64, c->comm, NULL)) return fail(RSF_ERR_DEVICE, "rsf_pool_allgather: ncclAllGather failed");
+  } else if (recv != send) {
+    memmove(recv, send, (size_t)count * sizeof(double));
+  }
   return RSF_OK;
 }
 
 int rsf_pool_allreduce_sum(rsf_ctx *c, double *buf, int64_t count) {
   if (!c || !buf || count < 1) return fail(RSF_ERR_INVALID, "rsf_pool_allreduce_sum: bad argument");
   if (!c->world) return fail(RSF_ERR_STATE, "rsf_pool_allreduce_sum: call rsf_comm_init first");
+  if (c->comm && g_nccl.all_reduce(buf, buf, (size_t)count, NCCL_FLOAT64, NCCL_SUM, c->comm, NULL))
+    return fail(RSF_ERR_DEVICE, "rsf_pool_allreduce_sum: ncclAllReduce failed");
+  return RSF_OK;
+}
+
+static int check_group(rsf_ctx *const *ctxs, int32_t n, const char *who, int need_comm) {
+  char msg[160];
+  if (!ctxs || n < 1) { snprintf(msg, sizeof msg, "%s: bad argument", who); return fail(RSF_ERR_INVALID, msg); }
+  for (int32_t i = 0; i < n; ++i) {
+    if (!ctxs[i]) { snprintf(msg, sizeof msg, "%s: ctxs[%d] is NULL", who, i); return fail(RSF_ERR_INVALID, msg); }
+    for (int32_t j = 0; j < i; ++j)
+      if (ctxs[j] == ctxs[i]) { snprintf(msg, sizeof msg, "%s: ctxs[%d] and ctxs[%d] are the same ctx", who, j, i); return fail(RSF_ERR_INVALID, msg); }
+    if (need_comm && (ctxs[i]->world != n || ctxs[i]->rank != i || !ctxs[i]->comm)) {
+      snprintf(msg, sizeof msg, "%s: ctxs[%d] is not rank %d of a %d-rank group made by rsf_comm_init_all", who, i, i, n);
+      return fail(RSF_ERR_STATE, msg);
+    }
+  }
+  return RSF_OK;
+}
+
+int rsf_comm_init_all(rsf_ctx *const *ctxs, int32_t n) {
+  int rc = check_group(ctxs, n, "rsf_comm_init_all", 0);
+  if (rc) return rc;
+  for (int32_t i = 0; i < n; ++i)
+    if (ctxs[i]->world) return fail(RSF_ERR_STATE, "rsf_comm_init_all: a ctx already has a communicator (rsf_comm_destroy first)");
+  if (!have_nccl())
+    return fail(RSF_ERR_UNSUPPORTED, "rsf_comm_init_all: the CPU oracle needs RSF_RCCL_LIB (a host-memory implementation of the nccl entry points)");
+  void *comms[64];
+  int devs[64] = {0};
+  if (n > 64) return fail(RSF_ERR_INVALID, "rsf_comm_init_all: at most 64 ctxs");
+  if (g_nccl.comm_init_all(comms, n, devs)) return fail(RSF_ERR_DEVICE, "rsf_comm_init_all: ncclCommInitAll failed");
+  for (int32_t i = 0; i < n; ++i) { ctxs[i]->comm = comms[i]; ctxs[i]->world = n; ctxs[i]->rank = i; }
+  return RSF_OK;
+}
+
+int rsf_pool_allgather_all(rsf_ctx *const *ctxs, int32_t n, const double *const *send, int64_t count, double *const *recv) {
+  int rc = check_group(ctxs, n, "rsf_pool_allgather_all", 1);
+  if (rc) return rc;
+  if (!send || !recv || count < 1) return fail(RSF_ERR_INVALID, "rsf_pool_allgather_all: bad argument");
+  for (int32_t i = 0; i < n; ++i)
+    if (!send[i] || !recv[i]) return fail(RSF_ERR_INVALID, "rsf_pool_allgather_all: a send / recv pointer is NULL");
+  g_nccl.group_start();
+  for (int32_t i = 0; i < n; ++i)
+    if (g_nccl.all_gather(send[i], recv[i], (size_t)count, NCCL_FLOAT64, ctxs[i]->comm, NULL)) {
+      g_nccl.group_end();
+      return fail(RSF_ERR_DEVICE, "rsf_pool_allgather_all: ncclAllGather failed");
+    }
+  if (g_nccl.group_end()) return fail(RSF_ERR_DEVICE, "rsf_pool_allgather_all: ncclGroupEnd failed");
+  return RSF_OK;
+}
+
+int rsf_pool_allreduce_sum_all(rsf_ctx *const *ctxs, int32_t n, double *const *bufs, int64_t count) {
+  int rc = check_group(ctxs, n, "rsf_pool_allreduce_sum_all", 1);
+  if (rc) return rc;
+  if (!bufs || count < 1) return fail(RSF_ERR_INVALID, "rsf_pool_allreduce_sum_all: bad argument");
+  for (int32_t i = 0; i < n; ++i)
+    if (!bufs[i]) return fail(RSF_ERR_INVALID, "rsf_pool_allreduce_sum_all: a buffer pointer is NULL");
+  g_nccl.group_start();
+  for (int32_t i = 0; i < n; ++i)
+    if (g_nccl.all_reduce(bufs[i], bufs[i], (size_t)count, NCCL_FLOAT64, NCCL_SUM, ctxs[i]->comm, NULL)) {
+      g_nccl.group_end();
+      return fail(RSF_ERR_DEVICE, "rsf_pool_allreduce_sum_all: ncclAllReduce failed");
+    }
+  if (g_nccl.group_end()) return fail(RSF_ERR_DEVICE, "rsf_pool_allreduce_sum_all: ncclGroupEnd failed");
   return RSF_OK;
 }
 

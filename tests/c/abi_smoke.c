@@ -48,6 +48,41 @@ int main(void) {
   for (int i = 0; i < ITERS * C; ++i) same = same && pool[i] == tq[i];
   CHECK(rsf_comm_destroy(ctx));
   printf("pool %s\n", same ? "ok" : "MISMATCH");
+  /* TWO ctxs driven by this one thread (rsf_comm_init_all + the grouped collectives): each samples its half of the
+   * chains under its chain_offset, and the pooled rows must equal the one-ctx run above.  Two ranks on one device need
+   * the test stub (RSF_RCCL_LIB = tests/c/fake_rccl.c); on a multi-GPU node give each ctx its own cfg.device instead. */
+  if (getenv("RSF_RCCL_LIB")) {
+    enum { H = C / 2 };
+    static double tqh[2][ITERS * H], poolh[2][ITERS * C];
+    rsf_ctx *cx[2];
+    for (int r = 0; r < 2; ++r) {
+      CHECK(rsf_create(&cfg, &cx[r]));
+      CHECK(rsf_set_model(cx[r], &m));
+      rsf_mcmc_config mh = mc;
+      mh.n_chains = H;
+      mh.chain_offset = r * H;
+      CHECK(rsf_mcmc_init(cx[r], &mh, q0 + r * H, data));
+      CHECK(rsf_mcmc_run(cx[r], ITERS, tqh[r], NULL, NULL));
+    }
+    const double *snd[2] = {tqh[0], tqh[1]};
+    double *rcv[2] = {poolh[0], poolh[1]};
+    double red[2][2] = {{1.0, 2.0}, {10.0, 20.0}};
+    double *rb[2] = {red[0], red[1]};
+    CHECK(rsf_comm_init_all(cx, 2));
+    CHECK(rsf_pool_allgather_all(cx, 2, snd, ITERS * H, rcv));
+    CHECK(rsf_pool_allreduce_sum_all(cx, 2, rb, 2));
+    int same2 = 1;
+    for (int r = 0; r < 2; ++r) {
+      same2 = same2 && red[r][0] == 11.0 && red[r][1] == 22.0;
+      for (int g = 0; g < 2; ++g)
+        for (int it = 0; it < ITERS; ++it)
+          for (int i = 0; i < H; ++i) same2 = same2 && rcv[r][g * (ITERS * H) + it * H + i] == tq[it * C + g * H + i];
+    }
+    for (int r = 0; r < 2; ++r) { CHECK(rsf_comm_destroy(cx[r])); CHECK(rsf_destroy(cx[r])); }
+    printf("pool2 %s\n", same2 ? "ok" : "MISMATCH");
+  } else {
+    printf("pool2 skipped\n");
+  }
   CHECK(rsf_destroy(ctx));
   free(acc); free(data);
   return 0;

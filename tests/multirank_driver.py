@@ -1,0 +1,169 @@
+#!/usr/bin/env python3
+"""
+World > 1 through the C ABI's own collectives, in ONE process — run as a child process by tests/test_multirank.py with
+RSF_RCCL_LIB pointing at the test stub tests/c/fake_rccl.c (real RCCL refuses two ranks on one device, and the CPU
+checker has no device at all; the stub must be chosen before the library binds RCCL, hence a fresh process).
+
+  python tests/multirank_driver.py --lib hip|oracle --mem host|device --params 1|3
+
+For world in (2, 4, 8): `world` ctxs each sample their chain_offset shard of the same global problem, then pool
+  (a) with one thread per rank:   rsf_comm_unique_id / rsf_comm_init (blocking, collective) / rsf_pool_allgather /
+                                  rsf_pool_allreduce_sum / rsf_comm_destroy, twice (destroy → re-init order);
+  (b) from a single thread:       rsf_comm_init_all / rsf_pool_allgather_all / rsf_pool_allreduce_sum_all,
+and every rank's receive buffer must hold rank r's block at [r], the chain-major pool must equal the single-ctx run of
+all chains BIT FOR BIT (Philox is keyed by global chain id), and the all-reduce must equal the rank-ordered sum.
+Prints one JSON line; exit status 0 only if every check held.  (Reference: the serial per-Dc loop RSF.py:1042-1044 is
+what this sharding replaces.)
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import threading
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+os.environ["RSF_ALLOW_CHECKER_ENGINE"] = "1"  # this script is test infrastructure: it may drive the CPU checker
+
+
+def to_np(x):
+    return np.asarray(x.cpu() if hasattr(x, "cpu") else x)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--lib", required=True, choices=["hip", "oracle"])
+    ap.add_argument("--mem", default="host", choices=["host", "device"])
+    ap.add_argument("--params", type=int, default=1, choices=[1, 3])
+    ap.add_argument("--chains", type=int, default=1536)
+    ap.add_argument("--worlds", default="2,4,8")
+    args = ap.parse_args()
+    assert os.environ.get("RSF_RCCL_LIB"), "the parent test sets RSF_RCCL_LIB to the stub"
+
+    import bayesian_markov_chain_monte_carlo_amd as pkg
+    from bayesian_markov_chain_monte_carlo_amd import dist as rdist
+    import rsf_oracle
+
+    if args.lib == "hip":
+        lib = pkg._abi.load()
+        assert lib.rsf_backend() == b"hip-gfx950"
+    else:
+        lib = pkg._abi.bind(ctypes.CDLL(rsf_oracle.lib_path()))
+        assert args.mem == "host"
+
+    def engine():
+        return pkg.Engine(lib=lib, mem=args.mem)
+
+    d, C, n_iters = args.params, args.chains, 6
+    model = rsf_oracle.ModelSpec(120)
+    rng = np.random.default_rng(11)
+    q0 = np.column_stack([rng.uniform(600.0, 1800.0, C), np.full(C, 0.011), np.full(C, 0.014)])[:, :d]
+    lo, hi = [0.0, 0.005, 0.005][:d], [1.0e4, 0.02, 0.03][:d]
+    kw = dict(seed=77, prior_len=3 if d == 1 else 0, adapt_mode="am", adapt_interval=3)
+    checks, failures = 0, []
+
+    def check(ok, what):
+        nonlocal checks
+        checks += 1
+        if not ok:
+            failures.append(what)
+
+    with engine() as e:
+        e.set_model(model, 1)
+        _, acc = e.forward([1000.0])
+        acc = to_np(acc)[:, 0]
+        data = acc + np.abs(acc) * rng.standard_normal(acc.shape[0])
+        e.mcmc_init(q0, data, lo, hi, chain_offset=0, **kw)
+        if d == 3:  # (X^T X)^-1 is near-singular for the joint problem: explicit start covariance, as bench.py does
+            e.set_state(V=np.tile(np.diag([20.0 ** 2, 1e-4 ** 2, 1e-4 ** 2]), (C, 1, 1)))
+        single = to_np(e.mcmc_run(n_iters, traces=("q",))[0])
+        e.sync()
+
+    for world in [int(w) for w in args.worlds.split(",")]:
+        per = C // world
+        engines, blocks = [], []
+        for r in range(world):
+            e = engine()
+            e.set_model(model, 1)
+            e.mcmc_init(q0[r * per:(r + 1) * per], data, lo, hi, chain_offset=r * per, **kw)
+            if d == 3:
+                e.set_state(V=np.tile(np.diag([20.0 ** 2, 1e-4 ** 2, 1e-4 ** 2]), (per, 1, 1)))
+            tq = e.mcmc_run(n_iters, traces=("q",))[0]
+            e.sync()
+            engines.append(e)
+            blocks.append(tq)
+        host_blocks = [to_np(b) for b in blocks]
+        sums = [np.array([b.sum(), (b * b).sum(), float(b.size), float(r + 1)]) for r, b in enumerate(host_blocks)]
+        want_sum = np.zeros(4)
+        for s in sums:  # rank order, like the stub (and like a ring would not: the check is on OUR code, not on RCCL's tree)
+            want_sum = want_sum + s
+
+        def verify(outs, reduced, tag):
+            for r, out in enumerate(outs):
+                out = to_np(out)
+                check(out.shape == (world,) + host_blocks[0].shape, f"{tag} world {world} rank {r}: receive shape {out.shape}")
+                for src in range(world):
+                    check(np.array_equal(out[src], host_blocks[src]), f"{tag} world {world} rank {r}: block {src} differs")
+                check(np.array_equal(rdist.pool_to_chain_major(out), single), f"{tag} world {world} rank {r}: pool != single-ctx run")
+            for r, red in enumerate(reduced):
+                check(np.array_equal(to_np(red), want_sum), f"{tag} world {world} rank {r}: all-reduce {to_np(red)} != {want_sum}")
+
+        # (a) one thread per rank, the blocking collective init — twice: destroy and re-init must work
+        for round_ in range(2):
+            uid = engines[0].comm_unique_id()
+            outs, reduced, errs = [None] * world, [None] * world, []
+
+            def work(r):
+                try:
+                    e = engines[r]
+                    e.comm_init(world, r, uid)
+                    outs[r] = e.pool_allgather(blocks[r])
+                    reduced[r] = e.pool_allreduce_sum(sums[r].copy())
+                    e.sync()
+                    e.comm_destroy()
+                except Exception as exc:  # noqa: BLE001 — reported below
+                    errs.append(f"rank {r}: {exc}")
+
+            ths = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+            for t in ths:
+                t.start()
+            for t in ths:
+                t.join(120)
+            check(not errs and not any(t.is_alive() for t in ths), f"threads world {world} round {round_}: {errs or 'hung'}")
+            if errs or any(t.is_alive() for t in ths):
+                break
+            verify(outs, reduced, f"threads/{round_}")
+
+        # (b) a single thread holding every ctx
+        if not failures:
+            pkg.Engine.comm_init_all(engines)
+            try:
+                pkg.Engine.comm_init_all(engines)
+                check(False, "second rsf_comm_init_all on live communicators was accepted")
+            except pkg.RsfError:
+                check(True, "")
+            outs = pkg.Engine.pool_allgather_all(engines, blocks)
+            reduced = pkg.Engine.pool_allreduce_sum_all(engines, [s.copy() for s in sums])
+            for e in engines:
+                e.sync()
+            verify(outs, reduced, "init_all")
+            try:  # a group must be complete and in rank order
+                pkg.Engine.pool_allgather_all(engines[::-1], blocks[::-1])
+                check(world == 1, "rsf_pool_allgather_all accepted ctxs out of rank order")
+            except pkg.RsfError:
+                check(True, "")
+            for e in engines:
+                e.comm_destroy()
+        for e in engines:
+            e.close()
+
+    print(json.dumps({"lib": args.lib, "mem": args.mem, "params": d, "checks": checks, "failures": failures[:10]}))
+    sys.exit(1 if failures else 0)
+
+
+if __name__ == "__main__":
+    main()

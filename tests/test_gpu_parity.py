@@ -719,6 +719,40 @@ def test_float32_solve_tolerance(pkg, oracle_mod):
                 assert abs(out["f32"][2] - out["f64"][2]) < 0.05
 
 
+@pytest.mark.parametrize("n,substeps,damping", [(500, 1, True), (4000, 1, True), (500, 2, False)])
+def test_float32_solve_against_the_float32_restatement(pkg, oracle_lib, oracle_mod, n, substeps, damping):
+    """The float32 kernel against an INDEPENDENT float32 checker: oracle/rsf_oracle.c restates the same float32 formulation in
+    plain C `float` with libm's exp2f / log2f (RSF_FLAG_FP32_SOLVE), so the two differ only by the last-place behaviour of
+    v_exp_f32 / v_log_f32 / v_rcp_f32 — amplified along the trajectory like any float32 rounding.  This pins every constant
+    and term of the kernel two orders below the 1e-3 band of the float32-vs-float64 sweep (a mis-scaled constant that
+    hid inside that band cannot hide here).  Tolerances are the measured spread with a factor ~3 (printed below)."""
+    rng = np.random.default_rng(80 + n)
+    m32 = _models(oracle_mod, n, substeps, damping)
+    m32.precision = "float32"
+    C = 600
+    dc = rng.uniform(100.0, 9000.0, C)
+    a = rng.uniform(0.008, 0.016, C)
+    b = a + rng.uniform(0.0, 0.008, C)
+    with pkg.Engine(mem="host") as g32, pkg.Engine(lib=oracle_lib) as c32, pkg.Engine(lib=oracle_lib) as c64:
+        for e in (g32, c32):
+            e.set_model(m32, substeps)
+        m32.precision = "float64"
+        c64.set_model(m32, substeps)
+        data = synthetic_data(c64)
+        sg, ag = g32.forward(dc, a=a, b=b, data=data, want_ssq=True, want_acc=True)
+        sc, ac = c32.forward(dc, a=a, b=b, data=data, want_ssq=True, want_acc=True)
+        s64, a64 = c64.forward(dc, a=a, b=b, data=data, want_ssq=True, want_acc=True)
+    e_ssq, e_traj = np.abs(sg / sc - 1), np.abs(ag - ac).max(axis=0) / np.abs(ac).max(axis=0)
+    band = np.abs(sc / s64 - 1)
+    print(f"float32 GPU vs float32 restatement, nsteps {n} S {substeps}: SSq max {e_ssq.max():.2e} median {np.median(e_ssq):.2e}; "
+          f"trajectory max {e_traj.max():.2e}; restatement vs float64: SSq max {band.max():.2e}")
+    assert np.isfinite(sg).all() and np.isfinite(sc).all()
+    assert not np.array_equal(ac, a64)            # the restatement really is a different arithmetic from the float64 one
+    assert band.max() < 1e-3                      # ... inside the sweep's band
+    assert e_ssq.max() < 3e-5 and np.median(e_ssq) < 2e-6
+    assert e_traj.max() < 1e-4
+
+
 def test_float32_tolerance_at_config5_shape():
     """BASELINE configs[4] per-GPU shard (131 072 chains, nsteps 4000, joint (Dc, a, b)) in BOTH precisions, same seeds —
     tools/fp32_sweep_cfg5.py with a shorter sampler run.  Bands (profiles/r02/fp32_sweep_cfg5.json holds the 400-iteration

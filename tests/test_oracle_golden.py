@@ -345,3 +345,37 @@ def test_pool_histogram_is_numpy_histogram(cpu_engine, pkg):
     for bad in (dict(nbins=0, lo=0.0, hi=1.0), dict(nbins=4097, lo=0.0, hi=1.0), dict(nbins=8, lo=1.0, hi=1.0), dict(nbins=8, lo=0.0, hi=np.inf)):
         with pytest.raises(pkg.RsfError):
             cpu_engine.pool_histogram(trace, **bad)
+
+
+def test_float32_restatement_is_float32_and_inside_the_sweep_band(pkg, oracle_lib, oracle_mod):
+    """oracle/rsf_oracle.c's RSF_FLAG_FP32_SOLVE path (the checker of the float32 kernel): genuinely single precision
+    (differs from the float64 restatement at the 1e-7..1e-4 level), inside the 1e-3 band of BASELINE config 5's sweep, and
+    — through the float64 restatement it is compared with — tied to the reference's golden trajectories."""
+    rng = np.random.default_rng(12)
+    C = 64
+    dc, a = rng.uniform(100.0, 9000.0, C), rng.uniform(0.008, 0.016, C)
+    b = a + rng.uniform(0.0, 0.008, C)
+    for n in (500, 2000):
+        m = oracle_mod.ModelSpec(n)
+        with pkg.Engine(lib=oracle_lib) as e64, pkg.Engine(lib=oracle_lib) as e32:
+            e64.set_model(m, 1)
+            m.precision = "float32"
+            e32.set_model(m, 1)
+            _, acc = e64.forward([1000.0])
+            data = acc[:, 0] * (1.0 + 0.5 * np.sin(np.arange(acc.shape[0])))
+            s64, a64 = e64.forward(dc, a=a, b=b, data=data, want_ssq=True, want_acc=True)
+            s32, a32 = e32.forward(dc, a=a, b=b, data=data, want_ssq=True, want_acc=True)
+            err = np.abs(s32 / s64 - 1)
+            assert 1e-9 < err.max() < 1e-3, err.max()
+            assert (np.abs(a32 - a64).max(axis=0) / np.abs(a64).max(axis=0)).max() < 2e-3
+            # every float32 sample is exactly representable in float32 (the interface stays float64)
+            assert np.array_equal(a32, a32.astype(np.float32).astype(np.float64))
+            # the sampler runs on top of it: float64 sensitivities and sigma^2_0, float32 initial SSq
+            q0 = np.full((8, 1), 1200.0)
+            for e in (e64, e32):
+                e.mcmc_init(q0, data, [0.0], [1e4], seed=5, prior_len=3)
+            (q6, s6, d6, V6), (q3, s3, d3, V3) = e64.get_state(), e32.get_state()
+            np.testing.assert_array_equal(V3, V6)
+            np.testing.assert_array_equal(d3, d6)
+            assert not np.array_equal(s3, s6) and np.allclose(s3, s6, rtol=1e-3)
+            assert e32.mcmc_run(5)[0].shape == (5, 8, 1)
