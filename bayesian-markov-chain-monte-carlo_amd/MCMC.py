@@ -17,11 +17,11 @@ import numpy as np
 
 if __package__:
     from . import _figures
-    from ._abi import ADAPT_MODES
+    from ._abi import ADAPT_MODES, RsfError
     from .engine import Engine
 else:  # flat layout: this directory on sys.path, the reference's own import style (main.py:44-46)
     import _figures
-    from _abi import ADAPT_MODES
+    from _abi import ADAPT_MODES, RsfError
     from engine import Engine
 
 
@@ -83,7 +83,11 @@ class MCMC:
                       prior_len=len(self.qpriors), adapt_mode=adapt_mode or self._adapt_mode(),
                       adapt_interval=self.adapt_interval)
 
-    # ---- reference sub-methods (public names kept) --------------------------------------
+    # ---- reference sub-methods (public names kept; each one runs its step on the device) -----------------------
+    # A caller that composes them the way the reference's own loop does (MCMC.py:494-527) gets the arithmetic of the fused
+    # kernel: acceptreject and update_standard_deviation are one replayed kernel iteration on the engine's chain,
+    # update_covariance_matrix the kernel's adaptation step on the given window.  The variates come from NumPy's global
+    # stream in the reference's order, exactly as in sample().
     def evaluate_model(self):
         if self.lstm_model:
             raise NotImplementedError("reduced-order-model hook: no such class exists in the reference")
@@ -97,33 +101,65 @@ class MCMC:
         ssq, _ = eng.forward([dc], data=np.asarray(self.data, dtype=np.float64).reshape(-1), want_ssq=True, want_acc=False)
         return ssq.reshape(1, 1)
 
+    def _scratch_chain(self, eng):
+        """The engine's one-chain sampler state the sub-methods work on (created by compute_initial_covariance, or here)."""
+        if eng.n_chains != 1 or eng.n_params != 1 or getattr(eng, "_chain_owner", None) is not self:
+            self._init_chains(eng, np.array([[float(self.qstart)]]))
+            eng._chain_owner = self
+        return eng
+
+    def _one_iteration(self, eng, q, ssq, std2, V, z, u, g):
+        """One kernel iteration (rsf_mcmc_replay) from an explicit chain state → (q, SSq, sigma^2, accepted) after it."""
+        eng.set_state(q=[[q]], ssq=[ssq], std2=[std2], V=[[[V]]])
+        tq, ts, ta = eng.mcmc_replay(np.array([[[z]]]), np.array([[u]]), np.array([[g]]))
+        return float(tq[0, 0, 0]), float(eng.get_state()[1][0]), float(ts[0, 0]), bool(ta[0, 0])
+
     def acceptreject(self, q_new, SSqprev, std2):
-        condition1 = q_new > self.qstart_limits[:, 0]
-        condition2 = q_new < self.qstart_limits[:, 1]
-        accept = np.all(condition1 & condition2, axis=0)
-        SSqnew = None
-        if accept:
-            SSqnew = self.SSqcalc(q_new)
-            with np.errstate(all="ignore"):
-                accept_prob = np.clip(0.5 * (SSqprev - SSqnew) / std2, -np.inf, 0)
-                accept = accept_prob > np.log(np.random.rand(1))[0]
-        return accept, SSqnew if accept else SSqprev
+        """(accept, SSq) for the proposal q_new (MCMC.py:268-333): the kernel's box test, forward solve and accept test, with
+        the uniform drawn from NumPy only when the proposal is inside the box (the reference's draw order)."""
+        eng = self._scratch_chain(self._engine())
+        q = float(np.asarray(q_new, dtype=np.float64).reshape(-1)[0])
+        lo, hi = float(self.qstart_limits[0, 0]), float(self.qstart_limits[0, 1])
+        u = 1.0
+        if q > lo and q < hi:
+            if self.replay_reference_rng:
+                np.random.randn(len(self.data))  # the N normals the reference's forward solve wastes (RateStateModel.py:392)
+            u = np.random.rand()
+        # proposal = q + chol(V) z with V = 0: the kernel proposes exactly q_new from the state (q_new, SSqprev, std2)
+        _, ssq, _, accept = self._one_iteration(eng, q, float(np.asarray(SSqprev).reshape(-1)[0]), float(std2), 0.0, 0.0, u, 1.0)
+        return accept, (np.array([[ssq]]) if accept else SSqprev)
 
     def update_standard_deviation(self, SSqprev):
-        aval = 0.5 * (self.n0 + len(self.data))
-        bval = 0.5 * (self.n0 * self.std2[-1] + SSqprev)
-        self.std2.append(1 / (np.random.standard_gamma(aval) * (1 / bval)))  # == 1/gamma.rvs(aval, scale=1/bval)
+        """Appends sigma^2 ~ InvGamma(0.5 (n0 + N), 0.5 (n0 sigma^2 + SSq)) (MCMC.py:129-160) — the kernel's Gibbs step: one
+        iteration whose proposal is out of bounds (z = +inf), so that nothing else of the chain moves."""
+        eng = self._scratch_chain(self._engine())
+        g = np.random.standard_gamma(0.5 * (self.n0 + len(self.data)))  # == gamma.rvs(aval, scale=1/bval) * bval
+        _, _, s2, _ = self._one_iteration(eng, float(self.qstart), float(np.asarray(SSqprev).reshape(-1)[0]), float(self.std2[-1]),
+                                          1.0, np.inf, 1.0, g)
+        self.std2.append(s2)
 
     def update_covariance_matrix(self, qparams):
-        Vnew = 2.38 ** 2 / len(self.qpriors.keys()) * np.cov(qparams[:, -self.adapt_interval:])
-        if qparams.shape[0] == 1:
-            Vnew = np.reshape(Vnew, (-1, 1))
-        return np.linalg.cholesky(Vnew).copy()
+        """chol(2.38^2 / len(qpriors.keys()) * cov(last adapt_interval samples)) (MCMC.py:162-204), on the device.  A list
+        prior has no .keys(): AttributeError, as in the reference (whose loop swallows it: the chain never adapts)."""
+        n_keys = len(self.qpriors.keys())
+        window = np.asarray(qparams, dtype=np.float64)[:, -self.adapt_interval:].T
+        try:
+            return self._engine().mcmc_adapt(window, "reference_dict", prior_len=n_keys)
+        except RsfError as ex:
+            if ex.code == -1:
+                raise np.linalg.LinAlgError("Matrix is not positive definite") from ex
+            raise
+
+    _vstart_override = None  # test hook: a value, or callable(mcmc) → value, that replaces the device's Vstart (tests/)
 
     def compute_initial_covariance(self):
         """std2[0] and Vstart (MCMC.py:244-266) from the device init kernel."""
         eng = self._engine()
         self._init_chains(eng, np.array([[float(self.qstart)]]))
+        eng._chain_owner = self
+        if self._vstart_override is not None:
+            ov = self._vstart_override
+            eng.set_state(V=np.reshape(float(ov(self) if callable(ov) else ov), (1, 1, 1)))
         _, _, std2, V = eng.get_state()
         self.std2 = [float(std2[0])]
         self.Vstart = V.reshape(1, 1).copy()

@@ -82,7 +82,10 @@ class RSF:
 
     def plot_dist(self, qparams, dc):
         """Kept samples beside their kernel density (RSF.py:717-746); the density is the device KDE of the pooled draws."""
-        kde = self.model.engine().pool_kde
+        def kde():  # resolved inside the figure's guard: an engine failure only skips the figure
+            return self.model.engine().pool_kde
+
+        kde._deferred = True
         return _figures.trace_with_density(qparams[0, :], f"$d_c={dc:.2f}\\,\\mu m$ with {self.format} formatting", kde)
 
     def perform_sampling_and_plotting(self, data, dc, nsamples, model_lstm):

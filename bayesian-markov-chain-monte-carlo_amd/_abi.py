@@ -83,6 +83,7 @@ _P = c_void_p  # array arguments travel as raw addresses (host ndarray or device
 PROTOTYPES = {
     "rsf_version": (c_int, []),
     "rsf_backend": (c_char_p, []),
+    "rsf_build_id": (c_char_p, []),
     "rsf_last_error": (c_char_p, []),
     "rsf_device_count": (c_int, []),
     "rsf_create": (c_int, [POINTER(Config), POINTER(c_void_p)]),
@@ -109,6 +110,7 @@ PROTOTYPES = {
     "rsf_pool_allgather_all": (c_int, [POINTER(c_void_p), c_int32, POINTER(c_void_p), c_int64, POINTER(c_void_p)]),
     "rsf_pool_allreduce_sum_all": (c_int, [POINTER(c_void_p), c_int32, POINTER(c_void_p), c_int64]),
     "rsf_philox4x32_10": (c_int, [POINTER(c_uint32), POINTER(c_uint32), POINTER(c_uint32)]),
+    "rsf_mcmc_adapt": (c_int, [c_int32, c_int32, _P, c_int32, c_int32, _P]),
     "rsf_mcmc_draws": (c_int, [c_uint64, c_int64, c_int64, c_int32, c_double, POINTER(c_double), POINTER(c_double), POINTER(c_double)]),
 }
 

@@ -20,11 +20,13 @@ def _pyplot():
 def chain_movie(chain, title, path, fps=30):
     """Grow the trace of one chain frame by frame and write it as a movie; → True if written."""
     chain = np.asarray(chain, dtype=np.float64).ravel()
+    fig = None
     try:
         from matplotlib.animation import FuncAnimation
 
         plt = _pyplot()
         fig, ax = plt.subplots()
+        # frames and x-range as the reference draws them: nsamples frames over (0, nsamples), MCMC.py:471-492
         ax.set(title=title, xlabel="Sample Index", ylabel="Sample Value", xlim=(0, chain.size - 1),
                ylim=(chain.min() - 1.0, chain.max() + 1.0))
         (trace,) = ax.plot([], [], lw=2)
@@ -35,19 +37,24 @@ def chain_movie(chain, title, path, fps=30):
             return (trace,)
 
         FuncAnimation(fig, draw, frames=chain.size - 1, blit=True).save(path, fps=fps, writer="ffmpeg")
-        plt.close(fig)
         return True
     except Exception as ex:  # no ffmpeg / no display / no matplotlib
         warnings.warn(f"MCMC animation skipped: {ex}")
         return False
+    finally:
+        if fig is not None:
+            _pyplot().close(fig)
 
 
 def trace_with_density(samples, title, density, points=1000):
     """Left: the kept samples in order.  Right: their density on a grid spanning the left panel's y-range, drawn sideways.
     `density(samples, grid) -> pdf` supplies the estimate (the device KDE).  → the figure, or None if skipped."""
     samples = np.asarray(samples, dtype=np.float64).ravel()
+    fig = None
     try:
         plt = _pyplot()
+        if callable(density) and getattr(density, "_deferred", False):
+            density = density()  # the engine is resolved inside the guard: a failure there only skips the figure
         fig, (left, right) = plt.subplots(1, 2, gridspec_kw=dict(width_ratios=(0.7, 0.15), wspace=0.15))
         fig.suptitle(title, fontsize=10)
         left.plot(samples, color="b", linewidth=1.0)
@@ -63,12 +70,15 @@ def trace_with_density(samples, title, density, points=1000):
         right.yaxis.set_visible(False)
         return fig
     except Exception as ex:
+        if fig is not None:
+            _pyplot().close(fig)  # a skipped figure must not stay registered with pyplot (one per Dc and inference)
         warnings.warn(f"posterior figure skipped: {ex}")
         return None
 
 
 def series_figure(t, acc, dc, t_start, t_final):
     """One clean acceleration series (RSF.plot_time_series)."""
+    fig = None
     try:
         plt = _pyplot()
         fig, ax = plt.subplots()
@@ -79,5 +89,7 @@ def series_figure(t, acc, dc, t_start, t_final):
         ax.legend()
         return fig
     except Exception as ex:
+        if fig is not None:
+            _pyplot().close(fig)
         warnings.warn(f"time-series figure skipped: {ex}")
         return None

@@ -693,6 +693,18 @@ __device__ __forceinline__ void sym_inverse(const double *A, double *Ai) {
   }
 }
 
+// update_covariance_matrix, MCMC.py:200-204: scale * np.cov(window) (ddof = 1) from the window's shifted sums
+// ws[p] = sum (q_p - ref_p), wq[p][r] = sum (q_p - ref_p)(q_r - ref_r) over nn samples, and its lower Cholesky factor.
+// false: not positive definite (np.linalg.cholesky raises, the caller keeps its covariance, MCMC.py:524-527).
+template <int D>
+__device__ __forceinline__ bool window_covariance(const double *ws, const double *wq, double nn, double scale, double *Vn, double *Ln) {
+#pragma unroll
+  for (int p = 0; p < D; ++p)
+#pragma unroll
+    for (int r = 0; r < D; ++r) Vn[p * D + r] = scale * ((wq[p * D + r] - ws[p] * ws[r] / nn) / (nn - 1.0));
+  return chol_lower<D>(Vn, Ln);
+}
+
 // wave64 sum via DPP-free shuffles; result valid in lane 0
 __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
 #pragma unroll

@@ -481,6 +481,10 @@ extern "C" {
 
 int rsf_version(void) { return RSF_ABI_VERSION; }
 const char *rsf_backend(void) { return "hip-gfx950"; }
+#ifndef RSF_BUILD_ID  // csrc/Makefile passes the SHA-256 prefix of the kernel sources
+#define RSF_BUILD_ID "unknown"
+#endif
+const char *rsf_build_id(void) { return RSF_BUILD_ID; }
 const char *rsf_last_error(void) { return g_err; }
 
 int rsf_device_count(void) {
@@ -882,7 +886,7 @@ int rsf_pool_histogram(rsf_ctx *c, int64_t n, const double *x, int64_t stride, i
   HIP_TRY(hipMemsetAsync(ws.p, 0, (size_t)nb * sizeof(unsigned long long), c->stream));
   const int blocks = (int)std::min<int64_t>(kPoolBlocks, (n + kMaxBlock - 1) / kMaxBlock);
   hipLaunchKernelGGL(pool_hist_kernel, dim3(blocks), dim3(kMaxBlock), (size_t)nb * sizeof(unsigned int), c->stream, n, (const double *)dx,
-                     stride, (int)nbins, lo, hi, (double)nbins / (hi - lo), (unsigned long long *)ws.p);
+                     stride, (int)nbins, lo, hi, (double)nbins / (hi - lo), (hi - lo) / (double)nbins, (unsigned long long *)ws.p);
   hipLaunchKernelGGL(pool_hist_finish_kernel, dim3((nb + kMaxBlock - 1) / kMaxBlock), dim3(kMaxBlock), 0, c->stream, nb,
                      (const unsigned long long *)ws.p, (double *)dout);
   if ((rc = copy_back(c, 2, counts, (size_t)nb * sizeof(double)))) return rc;
@@ -1084,6 +1088,27 @@ int rsf_mcmc_draws(uint64_t seed, int64_t chain, int64_t iteration, int32_t d, d
   if (z) for (int p = 0; p < d; ++p) z[p] = h[p];
   if (u) *u = h[3];
   if (g) *g = h[4];
+  return RSF_OK;
+}
+
+int rsf_mcmc_adapt(int32_t d, int32_t n, const double *window, int32_t adapt_mode, int32_t prior_len, double *V_out) {
+  if ((d != 1 && d != 3) || n < 1 || !window || !V_out || (adapt_mode != RSF_ADAPT_REFERENCE_DICT && adapt_mode != RSF_ADAPT_AM))
+    return fail(RSF_ERR_INVALID, "rsf_mcmc_adapt: bad argument");
+  if (adapt_mode == RSF_ADAPT_REFERENCE_DICT && d != 1)
+    return fail(RSF_ERR_UNSUPPORTED, "rsf_mcmc_adapt: reference_dict adaptation is defined for 1 parameter only");
+  double *dev = nullptr, h[10];
+  const size_t wb = (size_t)n * d * sizeof(double);
+  HIP_TRY(hipMalloc(&dev, wb + sizeof h));
+  hipError_t e = hipMemcpy(dev + 10, window, wb, hipMemcpyHostToDevice);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(probe_adapt_kernel, dim3(1), dim3(64), 0, nullptr, (int)d, (int)n, (const double *)(dev + 10), (int)adapt_mode,
+                       2.38 * 2.38 / (double)(prior_len > 0 ? prior_len : 2), dev);
+    e = hipMemcpy(h, dev, sizeof h, hipMemcpyDeviceToHost);
+  }
+  (void)hipFree(dev);
+  if (e != hipSuccess) return fail(RSF_ERR_DEVICE, "rsf_mcmc_adapt: %s", hipGetErrorString(e));
+  if (h[d * d] == 0.0) return fail(RSF_ERR_INVALID, "rsf_mcmc_adapt: the window's covariance is not positive definite");
+  for (int i = 0; i < d * d; ++i) V_out[i] = h[i];
   return RSF_OK;
 }
 

@@ -506,22 +506,14 @@ __global__ void __launch_bounds__(kMaxBlock, kMinBlocks) mcmc_kernel(Consts K, M
           if (A.adapt_mode == RSF_ADAPT_REFERENCE_DICT) {
             // d := len(qpriors.keys()) (2 for {1: lo, 2: hi}), and the Cholesky FACTOR becomes the next covariance
             // (one-parameter chains only: rsf_mcmc_init refuses the mode for D = 3)
-            Vn[0] = A.dict_scale * ((wq[0] - ws[0] * ws[0] / nn) / (nn - 1.0));
-            if (rsf::chol_lower<1>(Vn, Ln)) V1 = Ln[0];
-          } else {
+            if (rsf::window_covariance<1>(ws, wq, nn, A.dict_scale, Vn, Ln)) V1 = Ln[0];
+          } else if (rsf::window_covariance<D>(ws, wq, nn, 2.38 * 2.38 / (double)D, Vn, Ln)) {
+            if constexpr (D == 1) {
+              V1 = Vn[0];
+            } else {
 #pragma unroll
-            for (int p = 0; p < D; ++p)
-#pragma unroll
-              for (int r = 0; r < D; ++r)
-                Vn[p * D + r] = 2.38 * 2.38 / (double)D * ((wq[p * D + r] - ws[p] * ws[r] / nn) / (nn - 1.0));
-            if (rsf::chol_lower<D>(Vn, Ln)) {
-              if constexpr (D == 1) {
-                V1 = Vn[0];
-              } else {
-#pragma unroll
-                for (int e = 0; e < D * D; ++e) A.V[e * A.C + i] = Vn[e];
-                store_factor(Ln);
-              }
+              for (int e = 0; e < D * D; ++e) A.V[e * A.C + i] = Vn[e];
+              store_factor(Ln);
             }
           }
         }
@@ -550,6 +542,37 @@ __global__ void __launch_bounds__(kMaxBlock, kMinBlocks) mcmc_kernel(Consts K, M
     if (s1) atomicAdd(&A.stats[1], s1);
     if (s2) atomicAdd(&A.stats[2], s2);
   }
+}
+
+// rsf_mcmc_adapt: update_covariance_matrix (MCMC.py:200-204) of a window of samples win[n][d] with the sampler's own arithmetic
+// (shifted sums about the window's first sample, rsf::window_covariance).  out[0 .. d*d) = the next "Vold" of the
+// reference's loop — reference_dict: the Cholesky FACTOR (MCMC.py:203-204, 525); am: the covariance — out[d*d] = 1 if
+// positive definite, else 0.
+template <int D>
+__device__ void adapt_window(int n, const double *win, int mode, double dict_scale, double *out) {
+  double ws[D], wq[D * D], Vn[D * D], Ln[D * D];
+#pragma unroll
+  for (int p = 0; p < D; ++p) ws[p] = 0.0;
+#pragma unroll
+  for (int e = 0; e < D * D; ++e) wq[e] = 0.0;
+  for (int k = 0; k < n; ++k)
+#pragma unroll
+    for (int p = 0; p < D; ++p) {
+      ws[p] += win[k * D + p] - win[p];
+#pragma unroll
+      for (int r = 0; r < D; ++r) wq[p * D + r] += (win[k * D + p] - win[p]) * (win[k * D + r] - win[r]);
+    }
+  const bool dict = mode == RSF_ADAPT_REFERENCE_DICT;
+  const bool ok = n >= 2 && rsf::window_covariance<D>(ws, wq, (double)n, dict ? dict_scale : 2.38 * 2.38 / (double)D, Vn, Ln);
+#pragma unroll
+  for (int e = 0; e < D * D; ++e) out[e] = dict ? Ln[e] : Vn[e];
+  out[D * D] = ok ? 1.0 : 0.0;
+}
+
+__global__ void probe_adapt_kernel(int d, int n, const double *win, int mode, double dict_scale, double *out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  if (d == 1) adapt_window<1>(n, win, mode, dict_scale, out);
+  else adapt_window<3>(n, win, mode, dict_scale, out);
 }
 
 // [n][d] <-> [d][n] between the C ABI's per-chain layout and the kernels' structure of arrays (d = 3 only; for one
@@ -599,25 +622,34 @@ pool_moments_kernel(int64_t n, const double *__restrict__ x, int64_t stride, dou
 
 // Fixed-bin histogram (rsf_pool_histogram): HBM-bound, one pass.  Every workgroup counts into an LDS copy of the bins
 // (ds_add_u32), then adds its non-empty bins to the global 64-bit counters — integer atomics, so the result does not
-// depend on the order of arrival.  Bin index = floor((x - lo) * scale), scale = nbins/(hi - lo) from the host: one
-// subtraction and one product, no contraction possible, hence bit-identical to the CPU restatement.
+// depend on the order of arrival.  The bin of a sample is numpy.histogram's, edge cases included: a first guess
+// floor((x - lo) * nbins/(hi - lo)), then numpy's own correction against the bin EDGES np.linspace(lo, hi, nbins + 1)
+// (edge b = b * step + lo, two roundings — formed here with explicitly unfused multiply and add), so that a sample
+// sitting exactly on an edge — a chain that rejects repeats values like q0 — lands where numpy puts it.
 constexpr int kHistMaxBins = 4096;
 
-__device__ __forceinline__ int hist_bin(double v, double lo, double hi, double scale, int nbins) {
+__device__ __forceinline__ double hist_edge(int b, double lo, double hi, double step, int nbins) {
+  return b == nbins ? hi : __dadd_rn(__dmul_rn((double)b, step), lo);
+}
+
+__device__ __forceinline__ int hist_bin(double v, double lo, double hi, double scale, double step, int nbins) {
   if (v < lo) return 0;
   if (!(v <= hi)) return nbins + 1;                      // above hi, or NaN
-  const int b = (int)floor((v - lo) * scale);
-  return 1 + (b < nbins ? b : nbins - 1);                // v == hi (or rounding at the upper edge) -> last bin
+  int b = (int)((v - lo) * scale);
+  b = b < nbins ? b : nbins - 1;                         // v == hi (or rounding at the upper edge) -> last bin
+  if (v < hist_edge(b, lo, hi, step, nbins)) --b;        // the guess is within one bin of the truth; the edges decide
+  if (b != nbins - 1 && v >= hist_edge(b + 1, lo, hi, step, nbins)) ++b;
+  return 1 + b;
 }
 
 __global__ void __launch_bounds__(kMaxBlock)
-pool_hist_kernel(int64_t n, const double *__restrict__ x, int64_t stride, int nbins, double lo, double hi, double scale,
+pool_hist_kernel(int64_t n, const double *__restrict__ x, int64_t stride, int nbins, double lo, double hi, double scale, double step,
                  unsigned long long *__restrict__ counts) {
   extern __shared__ unsigned int hbins[];
   for (int b = threadIdx.x; b < nbins + 2; b += blockDim.x) hbins[b] = 0u;
   __syncthreads();
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-    atomicAdd(&hbins[hist_bin(x[i * stride], lo, hi, scale, nbins)], 1u);
+    atomicAdd(&hbins[hist_bin(x[i * stride], lo, hi, scale, step, nbins)], 1u);
   __syncthreads();
   for (int b = threadIdx.x; b < nbins + 2; b += blockDim.x)
     if (hbins[b]) atomicAdd(&counts[b], (unsigned long long)hbins[b]);

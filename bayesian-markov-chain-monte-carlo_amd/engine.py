@@ -54,16 +54,17 @@ def _model_struct(model, substeps):
 
 
 class Engine:
-    def __init__(self, lib=None, mem="host", device=-1, block_threads=0, cpu_threads=0, stream=None):
+    def __init__(self, lib=None, mem="host", device=-1, block_threads=0, cpu_threads=0, stream=None, checker=False):
         if lib is None:
             lib = _abi.load()
             _abi.require_device(lib)
-        elif lib.rsf_backend() != b"hip-gfx950" and os.environ.get("RSF_ALLOW_CHECKER_ENGINE") != "1":
+        elif lib.rsf_backend() != b"hip-gfx950" and not checker and os.environ.get("RSF_ALLOW_CHECKER_ENGINE") != "1":
             # `lib` exists so that the test-suite can drive the CPU oracle through this very class; nothing in the product may
-            # end up on it by accident: a non-HIP library is refused unless the caller has declared itself a checker
-            # (tests/conftest.py, __graft_entry__.smoke() and bench.py's cpu_baseline leg set the variable)
+            # end up on it by accident: a non-HIP library is refused unless THIS CALL declares itself a checker
+            # (checker=True: __graft_entry__.smoke(), bench.py's cpu_baseline leg, tools/) — the environment variable is
+            # the test-suite's process-wide form of the same declaration (tests/conftest.py) and is set nowhere else
             raise _abi.RsfError(-2, f"Engine(lib=...) was handed the {lib.rsf_backend().decode()!r} library: the product runs on "
-                                    "csrc/librsf_hip.so only (no CPU fallback); checkers set RSF_ALLOW_CHECKER_ENGINE=1")
+                                    "csrc/librsf_hip.so only (no CPU fallback); a checker passes checker=True")
         self.lib = lib
         self.mem = mem
         self.device = device
@@ -348,6 +349,17 @@ class Engine:
         ptrs = (ctypes.c_void_p * n)(*[Engine._ptr(x) for x in xs])
         _abi.check(lib, lib.rsf_pool_allreduce_sum_all(ctxs, n, ptrs, int(np.prod(xs[0].shape))))
         return xs
+
+    def mcmc_adapt(self, window, adapt_mode, prior_len=0):
+        """MCMC.update_covariance_matrix for one window of samples (n, d) on the device (rsf_mcmc_adapt) → the (d, d) matrix
+        the reference's loop would assign to Vold; raises RsfError(-1) where np.linalg.cholesky would raise."""
+        w = np.ascontiguousarray(window, dtype=np.float64)
+        w = w.reshape(w.shape[0], -1)
+        n, d = w.shape
+        out = np.empty((d, d))
+        mode = _abi.ADAPT_MODES[adapt_mode] if isinstance(adapt_mode, str) else int(adapt_mode)
+        _abi.check(self.lib, self.lib.rsf_mcmc_adapt(d, n, w.ctypes.data, mode, int(prior_len), out.ctypes.data))
+        return out
 
     # -- RNG helpers (tests) --------------------------------------------------------------
     def philox(self, ctr, key):

@@ -89,10 +89,10 @@ def cpu_baseline(model, data, target_s=12.0):
     import rsf_oracle
 
     lib = pkg._abi.bind(ctypes.CDLL(rsf_oracle.lib_path()))
-    os.environ["RSF_ALLOW_CHECKER_ENGINE"] = "1"  # this leg times the CPU restatement on purpose (reported baseline, not the product)
     cores = effective_cpus()
     chains = 256 * cores
-    with pkg.Engine(lib=lib, cpu_threads=cores) as e:
+    # checker=True: this leg times the CPU restatement on purpose (reported baseline, not the product)
+    with pkg.Engine(lib=lib, cpu_threads=cores, checker=True) as e:
         nout = e.set_model(model, 1)
         e.mcmc_init(np.full((chains, 1), 1000.0), data, [0.0], [1.0e4], seed=2025, prior_len=3)
         e.mcmc_run(1, traces=False)  # thread-pool warm-up
@@ -104,7 +104,7 @@ def cpu_baseline(model, data, target_s=12.0):
         e.mcmc_run(iters, traces=("q", "std2"))
         wall = time.perf_counter() - t0
     nsteps = model.num_tsteps
-    with pkg.Engine(lib=lib, cpu_threads=1) as e:  # per-core figure: a short single-thread run
+    with pkg.Engine(lib=lib, cpu_threads=1, checker=True) as e:  # per-core figure: a short single-thread run
         e.set_model(model, 1)
         e.mcmc_init(np.full((8, 1), 1000.0), data, [0.0], [1.0e4], seed=2025, prior_len=3)
         e.mcmc_run(1, traces=False)
@@ -178,6 +178,26 @@ def abi_pool_allgather(eng, local, expected_pool, rdist, timeout_s=90.0):
     return dict(res)
 
 
+def previous_round_line(workload_desc, value):
+    """The driver's record of the previous round's default run (BENCH_rNN.json at the repo root), so that a reader
+    diffing two rounds sees at the top level whether the headline workloads are the same and what the like-for-like
+    change is — round 2 had switched the default from configs[1] to configs[2] without saying so in the line."""
+    import glob
+    import re
+
+    files = sorted(glob.glob(os.path.join(ROOT, "BENCH_r*.json")), key=lambda f: int(re.search(r"_r(\d+)", f).group(1)))
+    if not files:
+        return None
+    try:
+        prev = json.load(open(files[-1])).get("parsed") or {}
+        pw, pv = prev["config"]["workload"], float(prev["value"])
+    except (KeyError, TypeError, ValueError, OSError):
+        return None
+    same = pw == workload_desc
+    return {"file": os.path.basename(files[-1]), "workload": pw, "value": pv, "comparable": same,
+            "ratio": value / pv if same else None}
+
+
 def cpu_model_name():
     try:
         for line in open("/proc/cpuinfo"):
@@ -239,8 +259,11 @@ def time_sampler(pkg, model, data, C, ips, steps, warmup, rank, barrier, d=1):
     return wall, kernel_ms, eng.stats(), eng, traces, nout
 
 
-def roofline_views(workload, custom, C, ips, nout, stats, kernel_ms, d=1, mode="RK4"):
-    """The two roofline views of one launch of the sampler kernel."""
+def roofline_views(workload, custom, C, ips, nout, stats, kernel_ms, d=1, mode="RK4", build_id=None):
+    """The two roofline views of one launch of the sampler kernel.  PMC figures stored in
+    profiles/pmc_traffic.json are attached only if they were collected on THIS build of the kernels (rsf_build_id(): the
+    hash of the kernel sources the loaded library was compiled from) and this launch shape; otherwise they are null and
+    the view says pmc_stale."""
     evaluated = stats["evaluated"] / max(1, stats["iters_done"] * C)
     per_launch_props = C * ips
     rk4_steps_per_launch = per_launch_props * (nout - 1) * evaluated
@@ -252,16 +275,21 @@ def roofline_views(workload, custom, C, ips, nout, stats, kernel_ms, d=1, mode="
     if os.path.exists(path) and not custom:
         with open(path) as f:
             t = json.load(f)
-        if t.get(workload + "_iters_per_step") == ips:   # PMC figures belong to this launch shape
-            pmc = {"traffic": t.get(workload), "valu_insts_per_rk4_step": t.get(workload + "_valu_per_rk4_step"),
-                   "pipe_busy": t.get(workload + "_pipe_busy"),
-                   "pmc_source": f"rocprofv3 PMC passes of this launch shape, {t.get(workload + '_source')} — stored, not measured in this run"}
+        if t.get(workload + "_iters_per_step") == ips and workload in t:   # PMC figures belong to this launch shape ...
+            if build_id is not None and t.get(workload + "_build_id") == build_id:  # ... and to the code that is running
+                pmc = {"traffic": t.get(workload), "valu_insts_per_rk4_step": t.get(workload + "_valu_per_rk4_step"),
+                       "pipe_busy": t.get(workload + "_pipe_busy"),
+                       "pmc_source": f"rocprofv3 PMC passes of this launch shape on this build ({build_id}), {t.get(workload + '_source')} — "
+                                     "stored, not measured in this run"}
+            else:
+                pmc = {"pmc_stale": True, "pmc_source": f"stored counters ({t.get(workload + '_source')}) are from build "
+                                                        f"{t.get(workload + '_build_id')}, the loaded library is {build_id}: not reported"}
     valu = {"bound": "valu_fp64", "achieved": tflops, "peak": PEAK_FP64_VALU_TFLOPS, "unit": "TFLOP/s",
             "frac": tflops / PEAK_FP64_VALU_TFLOPS, "traffic": pmc.get("traffic"),
             "kernel": f"mcmc_kernel<{d},damp,philox,{mode}>", "kernel_ms": kernel_ms,
             "flops_per_rk4_step": FLOPS_PER_RK4_STEP, "rk4_steps_per_s": rk4_steps_per_launch / (kernel_ms * 1e-3),
             "valu_insts_per_rk4_step": pmc.get("valu_insts_per_rk4_step"), "pipe_busy": pmc.get("pipe_busy"),
-            "pmc_source": pmc.get("pmc_source"),
+            "pmc_source": pmc.get("pmc_source"), "pmc_stale": bool(pmc.get("pmc_stale")),
             "peak_sustained": SUSTAINED_FMA_TFLOPS, "frac_of_sustained": tflops / SUSTAINED_FMA_TFLOPS,
             "issue_rate_vs_pure_fma_stream": (pmc["valu_insts_per_rk4_step"] * rk4_steps_per_launch / (kernel_ms * 1e-3) * 2.0 / 1e12
                                               / SUSTAINED_FMA_TFLOPS) if pmc.get("valu_insts_per_rk4_step") else None,
@@ -358,7 +386,8 @@ def main():
 
     if rank == 0:
         value = world * C * ips * args.steps * nsteps / wall
-        valu, hbm, evaluated = roofline_views(args.workload + variant, custom, C, ips, nout, stats, kernel_ms, d, mode)
+        build_id = pkg._abi.load().rsf_build_id().decode()
+        valu, hbm, evaluated = roofline_views(args.workload + variant, custom, C, ips, nout, stats, kernel_ms, d, mode, build_id)
         if mode != "RK4":
             valu["note"] = ("side measurement, not the headline arithmetic: " + ("the reference's adaptive DOP853 scheme — the unit of "
                             "rk4_steps_per_s is one OUTPUT INTERVAL (>= 1 step of 12 stages), flops are not counted, frac is nominal only"
@@ -367,7 +396,7 @@ def main():
             "metric": "ode_steps_x_chains_per_sec", "value": value, "unit": "ODE-steps*chains/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64" if args.precision == "float64" else "f32 solve, f64 sampler",
-            "data": "synthetic",
+            "data": "synthetic", "build_id": build_id,
             "config": {"workload": (wl["desc"] if not custom else f"custom: {C} chains x nsteps {nsteps}, fp64") + (f" [{mode}]" if mode != "RK4" else ""),
                        "chains_per_gpu": C, "nsteps": nsteps, "rk4_substeps": 1, "proposals_per_chain_per_step": ips,
                        "n_params": d, "adapt_mode": "none", "integrator": args.integrator, "parallelism": f"chains sharded over {world} GPU(s), no data-path collective",
@@ -375,6 +404,7 @@ def main():
                        "acceptance": stats["accepted"] / max(1, stats["iters_done"] * C)},
             "roofline": valu, "roofline_hbm": hbm,
         }
+        out["previous_round"] = previous_round_line(out["config"]["workload"], value)
         if allgather_ms is not None:
             out["pool_allgather_ms"] = allgather_ms
         if abi_pool is not None:
@@ -390,11 +420,11 @@ def main():
             k = max(3, min(args.steps, 10))
             model_o, data_o = synthetic_problem(wo["nsteps"])
             w_o, kms_o, st_o, eng_o, tr_o, nout_o = time_sampler(pkg, model_o, data_o, wo["chains"], ips, k, 2, 0, barrier)
-            valu_o, _, _ = roofline_views(other, False, wo["chains"], ips, nout_o, st_o, kms_o)
+            valu_o, _, _ = roofline_views(other, False, wo["chains"], ips, nout_o, st_o, kms_o, build_id=out["build_id"])
             out["also"] = {other: {"workload": wo["desc"], "value": wo["chains"] * ips * k * wo["nsteps"] / w_o,
                                    "unit": "ODE-steps*chains/s", "steps": k, "ms_per_step": w_o / k * 1e3,
                                    "roofline": {kk: valu_o[kk] for kk in ("bound", "achieved", "peak", "unit", "frac", "kernel_ms",
-                                                                          "valu_insts_per_rk4_step", "pipe_busy", "traffic")}}}
+                                                                          "valu_insts_per_rk4_step", "pipe_busy", "traffic", "pmc_stale")}}}
             eng_o.close()
             del tr_o
             torch.cuda.empty_cache()

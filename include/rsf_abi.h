@@ -122,6 +122,9 @@ typedef struct rsf_mcmc_config {
 /* ---- library level ---------------------------------------------------------------- */
 int rsf_version(void);
 const char *rsf_backend(void);    /* "hip-gfx950" | "oracle-cpu" */
+const char *rsf_build_id(void);   /* HIP library: first 16 hex digits of the SHA-256 of the kernel sources it was compiled from
+                                     (csrc/Makefile) — what stored profiler evidence is keyed by (profiles/pmc_traffic.json,
+                                     bench.py); the checker: "oracle" */
 const char *rsf_last_error(void); /* thread-local, never NULL */
 int rsf_device_count(void);       /* >= 0, or negative status */
 
@@ -207,7 +210,8 @@ int rsf_pool_kde(rsf_ctx *ctx, int64_t n, const double *x, int64_t stride, int32
 
 /* Fixed-bin histogram of n samples x[i*stride] over [lo, hi] (the summary path of SURVEY §8e: a few KB per GPU that
  * rsf_pool_allreduce_sum combines across ranks when the pool itself need not be materialised).  numpy.histogram
- * semantics: nbins equal bins, bin i = [lo + i w, lo + (i+1) w) with w = (hi-lo)/nbins, the last bin closed at hi.
+ * semantics, edge cases included: nbins equal bins between the edges np.linspace(lo, hi, nbins + 1), bin i = [edge_i,
+ * edge_i+1), the last bin closed at hi — a sample exactly on an edge is counted where numpy counts it.
  *   counts[0] = samples below lo, counts[1 .. nbins] = the bins, counts[nbins+1] = samples above hi or NaN.
  * Counts are exact integers stored as doubles (so that the double all-reduce sums them exactly); `counts` follows the
  * ctx mem_space; 1 <= nbins <= 4096. */
@@ -257,6 +261,15 @@ int rsf_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out
  * normals, the accept uniform and the Gamma(shape) variate.  Host-side, for tests. */
 int rsf_mcmc_draws(uint64_t seed, int64_t chain, int64_t iteration, int32_t n_params, double shape,
                    double *z, double *u, double *g);
+
+/* MCMC.update_covariance_matrix (MCMC.py:162-204) for ONE window of samples window[n][d] (the reference passes the last
+ * adapt_interval columns of qparams), computed on the device by the sampler's own adaptation arithmetic.  V_out[d][d] is
+ * what the reference's loop would assign to Vold (MCMC.py:525): RSF_ADAPT_REFERENCE_DICT — the Cholesky FACTOR of
+ * 2.38^2/prior_len * cov(window) (the quirk: it is then used as a covariance; d = 1 only; prior_len 0 => 2);
+ * RSF_ADAPT_AM — 2.38^2/d * cov(window).  RSF_ERR_INVALID when that matrix is not positive definite (where
+ * np.linalg.cholesky raises and the reference keeps its covariance, MCMC.py:524-527).  Host arrays; for callers that
+ * compose the sampler's sub-steps themselves. */
+int rsf_mcmc_adapt(int32_t n_params, int32_t n, const double *window, int32_t adapt_mode, int32_t prior_len, double *V_out);
 
 #ifdef __cplusplus
 }

@@ -135,6 +135,7 @@ struct rsf_ctx {
 
 int rsf_version(void) { return RSF_ABI_VERSION; }
 const char *rsf_backend(void) { return "oracle-cpu"; }
+const char *rsf_build_id(void) { return "oracle"; }
 const char *rsf_last_error(void) { return g_err; }
 int rsf_device_count(void) { return 0; }
 
@@ -785,18 +786,30 @@ int rsf_pool_kde(rsf_ctx *c, int64_t n, const double *x, int64_t stride, int32_t
 }
 
 /* Fixed-bin histogram, numpy.histogram semantics (include/rsf_abi.h): counts[0] below lo, counts[1..nbins], counts[nbins+1]
- * above hi or NaN.  Same index arithmetic as the device kernel: floor((x - lo) * (nbins/(hi - lo))). */
+ * above hi or NaN.  numpy's rule restated (numpy/lib/_histograms_impl.py, uniform bins): a first index from
+ * (x - lo)/(hi - lo) * nbins, then the correction against the bin edges np.linspace(lo, hi, nbins + 1) = b*step + lo
+ * (last edge = hi): one down if x < edge[b], one up if x >= edge[b+1] (except in the last bin, closed at hi). */
+static double hist_edge(int32_t b, double lo, double hi, double step, int32_t nbins) {
+  return b == nbins ? hi : (double)b * step + lo;   /* -ffp-contract=off: two roundings, like numpy */
+}
+
 int rsf_pool_histogram(rsf_ctx *c, int64_t n, const double *x, int64_t stride, int32_t nbins, double lo, double hi, double *counts) {
   if (!c || !x || !counts || n < 1 || stride < 1 || nbins < 1 || nbins > 4096 || !(hi > lo) || !isfinite(hi - lo))
     return fail(RSF_ERR_INVALID, "rsf_pool_histogram: bad argument (1 <= nbins <= 4096, finite lo < hi)");
-  const double scale = (double)nbins / (hi - lo);
+  const double step = (hi - lo) / (double)nbins;
   for (int32_t b = 0; b < nbins + 2; ++b) counts[b] = 0.0;
   for (int64_t i = 0; i < n; ++i) {
     const double v = x[i * stride];
     int32_t b;
     if (v < lo) b = 0;
     else if (!(v <= hi)) b = nbins + 1;
-    else { b = (int32_t)floor((v - lo) * scale); b = 1 + (b < nbins ? b : nbins - 1); }
+    else {
+      b = (int32_t)(((v - lo) / (hi - lo)) * (double)nbins);
+      if (b >= nbins) b = nbins - 1;
+      if (v < hist_edge(b, lo, hi, step, nbins)) --b;
+      if (b != nbins - 1 && v >= hist_edge(b + 1, lo, hi, step, nbins)) ++b;
+      b += 1;
+    }
     counts[b] += 1.0;
   }
   return RSF_OK;
@@ -958,6 +971,29 @@ int rsf_pool_allreduce_sum_all(rsf_ctx *const *ctxs, int32_t n, double *const *b
       return fail(RSF_ERR_DEVICE, "rsf_pool_allreduce_sum_all: ncclAllReduce failed");
     }
   if (g_nccl.group_end()) return fail(RSF_ERR_DEVICE, "rsf_pool_allreduce_sum_all: ncclGroupEnd failed");
+  return RSF_OK;
+}
+
+/* update_covariance_matrix, MCMC.py:200-204, for one window (the adaptation block of run_chain on a given set of samples) */
+int rsf_mcmc_adapt(int32_t d, int32_t n, const double *window, int32_t adapt_mode, int32_t prior_len, double *V_out) {
+  if ((d != 1 && d != 3) || n < 1 || !window || !V_out || (adapt_mode != RSF_ADAPT_REFERENCE_DICT && adapt_mode != RSF_ADAPT_AM))
+    return fail(RSF_ERR_INVALID, "rsf_mcmc_adapt: bad argument");
+  if (adapt_mode == RSF_ADAPT_REFERENCE_DICT && d != 1)
+    return fail(RSF_ERR_UNSUPPORTED, "rsf_mcmc_adapt: reference_dict adaptation is defined for 1 parameter only");
+  double mean[3] = {0, 0, 0}, cov[9], Vn[9], Ln[9];
+  for (int32_t k = 0; k < n; ++k)
+    for (int p = 0; p < d; ++p) mean[p] += window[k * d + p];
+  for (int p = 0; p < d; ++p) mean[p] /= (double)n;
+  for (int p = 0; p < d; ++p)
+    for (int r = 0; r < d; ++r) {
+      double s = 0.0;
+      for (int32_t k = 0; k < n; ++k) s += (window[k * d + p] - mean[p]) * (window[k * d + r] - mean[r]);
+      cov[p * d + r] = n > 1 ? s / (double)(n - 1) : 0.0;  /* np.cov, ddof = 1 */
+    }
+  const double scale = adapt_mode == RSF_ADAPT_REFERENCE_DICT ? 2.38 * 2.38 / (double)(prior_len > 0 ? prior_len : 2) : 2.38 * 2.38 / (double)d;
+  for (int e = 0; e < d * d; ++e) Vn[e] = scale * cov[e];
+  if (n < 2 || !chol_lower(Vn, d, Ln)) return fail(RSF_ERR_INVALID, "rsf_mcmc_adapt: the window's covariance is not positive definite");
+  memcpy(V_out, adapt_mode == RSF_ADAPT_REFERENCE_DICT ? Ln : Vn, sizeof(double) * d * d);
   return RSF_OK;
 }
 

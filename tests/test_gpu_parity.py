@@ -638,6 +638,14 @@ def test_pool_histogram(pkg, cpu_engine):
             assert ref.sum() == n
         with pytest.raises(pkg.RsfError):
             eh.pool_histogram(trace, 5000, 0.0, 1.0)
+        # samples exactly on the bin edges and one ulp either side: numpy.histogram itself is the reference here
+        for nbins, lo, hi in ((10, 0.0, 1.0), (100, 0.005, 0.02), (7, 0.008, 0.014), (1000, 900.0, 1100.0), (3, -1.0, 2.0)):
+            edges = np.linspace(lo, hi, nbins + 1)
+            x = np.concatenate([edges, np.nextafter(edges, -np.inf), np.nextafter(edges, np.inf), [0.3, 0.7, lo + 0.3 * (hi - lo)]])
+            ref, _ = np.histogram(x, nbins, (lo, hi))
+            got = eh.pool_histogram(x, nbins, lo, hi)
+            np.testing.assert_array_equal(got[1:-1], ref, err_msg=f"{(nbins, lo, hi)}")
+            np.testing.assert_array_equal(got, cpu_engine.pool_histogram(x, nbins, lo, hi))
 
 
 def test_observation_groups(gpu_engine, cpu_engine, oracle_mod):
@@ -725,7 +733,8 @@ def test_float32_solve_against_the_float32_restatement(pkg, oracle_lib, oracle_m
     plain C `float` with libm's exp2f / log2f (RSF_FLAG_FP32_SOLVE), so the two differ only by the last-place behaviour of
     v_exp_f32 / v_log_f32 / v_rcp_f32 — amplified along the trajectory like any float32 rounding.  This pins every constant
     and term of the kernel two orders below the 1e-3 band of the float32-vs-float64 sweep (a mis-scaled constant that
-    hid inside that band cannot hide here).  Tolerances are the measured spread with a factor ~3 (printed below)."""
+    hid inside that band cannot hide here).  Measured on MI355X (round 3): SSq max 3.1e-8, median 3e-9, trajectories max
+    3.6e-7 — asserted with a factor ~15."""
     rng = np.random.default_rng(80 + n)
     m32 = _models(oracle_mod, n, substeps, damping)
     m32.precision = "float32"
@@ -749,8 +758,8 @@ def test_float32_solve_against_the_float32_restatement(pkg, oracle_lib, oracle_m
     assert np.isfinite(sg).all() and np.isfinite(sc).all()
     assert not np.array_equal(ac, a64)            # the restatement really is a different arithmetic from the float64 one
     assert band.max() < 1e-3                      # ... inside the sweep's band
-    assert e_ssq.max() < 3e-5 and np.median(e_ssq) < 2e-6
-    assert e_traj.max() < 1e-4
+    assert e_ssq.max() < 5e-7 and np.median(e_ssq) < 5e-8
+    assert e_traj.max() < 5e-6
 
 
 def test_float32_tolerance_at_config5_shape():

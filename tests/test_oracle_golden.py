@@ -345,6 +345,16 @@ def test_pool_histogram_is_numpy_histogram(cpu_engine, pkg):
     for bad in (dict(nbins=0, lo=0.0, hi=1.0), dict(nbins=4097, lo=0.0, hi=1.0), dict(nbins=8, lo=1.0, hi=1.0), dict(nbins=8, lo=0.0, hi=np.inf)):
         with pytest.raises(pkg.RsfError):
             cpu_engine.pool_histogram(trace, **bad)
+    # samples sitting EXACTLY on bin edges (a chain that rejects repeats exact values such as q0, so this is not a null
+    # set): numpy re-checks its index guess against np.linspace's edges, and so must the library — floor((x - lo) * nbins /
+    # (hi - lo)) alone disagrees with numpy on 5 of these probes for (10, 0, 1) and on dozens for (100, 0.005, 0.02)
+    for nbins, lo, hi in ((10, 0.0, 1.0), (100, 0.005, 0.02), (7, 0.008, 0.014), (1000, 900.0, 1100.0), (3, -1.0, 2.0)):
+        edges = np.linspace(lo, hi, nbins + 1)
+        x = np.concatenate([edges, np.nextafter(edges, -np.inf), np.nextafter(edges, np.inf), [0.3, 0.7, lo + 0.3 * (hi - lo)]])
+        counts = cpu_engine.pool_histogram(x, nbins, lo, hi)
+        ref, _ = np.histogram(x, nbins, (lo, hi))
+        np.testing.assert_array_equal(counts[1:-1], ref, err_msg=f"{(nbins, lo, hi)}")
+        assert counts[0] == (x < lo).sum() and counts[-1] == (x > hi).sum()
 
 
 def test_float32_restatement_is_float32_and_inside_the_sweep_band(pkg, oracle_lib, oracle_mod):

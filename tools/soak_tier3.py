@@ -28,7 +28,6 @@ def batch_means_se(per_chain_means):
 def main():
     import torch
 
-    os.environ["RSF_ALLOW_CHECKER_ENGINE"] = "1"
     lib = pkg._abi.bind(ctypes.CDLL(rsf_oracle.lib_path()))
     model = pkg.RateStateModel(500)
     with pkg.Engine(mem="host") as e:
@@ -66,7 +65,7 @@ def main():
                       seconds=dt, ode_steps_x_chains_per_s=C * block * nblocks * 500 / dt)
     # --- oracle: 4096 chains x 1500 proposals (other seed), burn 500
     Co, n, burn = 4096, 1500, 500
-    with pkg.Engine(lib=lib) as e:
+    with pkg.Engine(lib=lib, checker=True) as e:
         e.set_model(model, 1)
         e.mcmc_init(np.full((Co, 1), 1000.0), data, [0.0], [1.0e4], seed=777, prior_len=3)
         t0 = time.perf_counter()

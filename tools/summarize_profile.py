@@ -66,6 +66,7 @@ def main():
         if lines:
             bench = json.loads(lines[-1])
             ips = bench["config"].get("proposals_per_chain_per_step")
+            summary["build_id"] = bench.get("build_id")  # rsf_build_id() of the library that ran under the profiler
             summary["bench_kernel_ms_hip_events"] = bench["roofline"].get("kernel_ms")
             bench_roof = bench["roofline"] if "rk4_steps_per_s" in bench["roofline"] else bench.get("roofline_valu")
             if bench_roof is not None:
@@ -87,6 +88,7 @@ def main():
         traffic[tag] = summary["hbm_bytes_per_launch"]["total_corrected"]
         traffic[tag + "_source"] = f"{dst}/{tag}_{build}_pmc.json"
         traffic[tag + "_iters_per_step"] = ips
+        traffic[tag + "_build_id"] = summary.get("build_id")
         traffic[tag + "_valu_per_rk4_step"] = summary.get("valu_insts_per_rk4_step")
         traffic[tag + "_pipe_busy"] = summary.get("pipe_busy")
         json.dump(traffic, open(tfile, "w"), indent=1)

@@ -20,7 +20,6 @@ import rsf_oracle  # noqa: E402  (the checker: this is a measurement tool, not t
 
 
 def main():
-    os.environ["RSF_ALLOW_CHECKER_ENGINE"] = "1"
     lib = pkg._abi.bind(ctypes.CDLL(rsf_oracle.lib_path()))
     rng = np.random.default_rng(11)
     out = {}
@@ -30,7 +29,7 @@ def main():
         dc = np.exp(rng.uniform(np.log(150.0), np.log(9000.0), C))
         a = rng.uniform(0.008, 0.016, C)
         b = a + rng.uniform(0.0, 0.008, C)
-        with pkg.Engine(mem="host") as g, pkg.Engine(lib=lib) as c:
+        with pkg.Engine(mem="host") as g, pkg.Engine(lib=lib, checker=True) as c:
             g.set_model(m, 1)
             c.set_model(m, 1)
             _, ref = c.forward([1000.0])
