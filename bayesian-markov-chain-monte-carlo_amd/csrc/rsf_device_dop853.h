@@ -5,9 +5,17 @@
 // order error estimators), step-size control with safety 0.9 and factors 0.3 .. 6 (beta = 0), at most 500 steps per
 // call, HMAX = interval length, HINIT on the first call and the predicted step size carried from call to call
 // (scipy keeps it in the work array).  After the first interval every call is normally ONE accepted step of
-// length delta_t, so lanes stay convergent.  The RHS is evaluated in full at the end points of every step and
-// incrementally from the step's start point at its eleven inner stages (friction_incr) — this mode is for fidelity to the
-// reference's numbers (agreement ~1e-12 with its trajectories), the fixed-step RK4 path is the fast one.  Tableau: include/rsf_dop853_tableau.h (generated from SciPy's table).
+// length delta_t, so lanes stay convergent.  That steady state is the fast path of call(): the RHS is evaluated in full
+// at the step's end point and incrementally from its start point at the eleven inner stages (friction_incr); every other
+// step goes through the general loop with full evaluations.  This mode is for fidelity to the reference's numbers
+// (agreement ~1e-12 with its trajectories), the fixed-step RK4 path is the fast one.
+// Tableau: include/rsf_dop853_tableau.h (generated from SciPy's table).
+//
+// What is NOT carried per stage: the third component.  V never feeds back into the RHS (RateStateModel.py:336-353), so
+// no stage needs the V derivatives of earlier stages; they enter only the step's closing sums (8th-order weights B and
+// the error estimators, stages 1 and 6..12).  Those sums are accumulated as each stage completes (VSums) instead of
+// keeping twelve values live — with the mu and theta derivatives that is 24 doubles per lane instead of 36, which is
+// what lets the sampler kernel hold the step in registers at two waves per SIMD.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -19,14 +27,28 @@ namespace rsf {
 namespace dp {
 
 constexpr double kRtol = 1e-6, kAtol = 1e-10;
+// dop853.f forms the 3rd-order estimator from the 8th-order sum: err2_i = (sum_j b_j k_j)_i - bhh1 k1 - bhh2 k9 - bhh3 k12
+// (= sum_j E3_j k_j with the tableau's E3 = B - bhh on those three stages): three products per component instead of eight.
+constexpr double kBhh1 = 0.244094488188976377952755905512, kBhh2 = 0.733846688281611857341361741547,
+                 kBhh3 = 0.0220588235294117647058823529412;
+// (tests/test_oracle_golden.py::test_dop853_bhh_constants checks them against the tableau's E3)
 
 struct LaneD {
   double inv_dc, kprime, inv_a, b;
+  double boa, c3;  // b/a and b/Dc - k': the fast path's folded constants (FastStep)
 };
 
-// loading velocity V_l(t), RateStateModel.py:327-329
+// loading velocity V_l(t) = V_ref (1 + exp(-t/20) sin(10 t)), RateStateModel.py:327-329, at a time that is not in the
+// table (HINIT's first interval, steps after a rejection).  sin(10 t) = sin(2 pi u), u = frac(10 t / 2 pi): 10 t / 2 pi stays
+// below ~100 over the model's time span, so the one rounding of the constant costs < 2e-14 in u and the sine agrees with
+// libm's to ~1e-13 absolute — against the 1e-9 this mode is held to — at a tenth of the registers and instructions of
+// the full-range argument reduction in OCML's sin (which alone cost the sampler kernel 80 B of scratch per lane).
 __device__ __forceinline__ double loading(const Consts &K, double t) {
-  return K.V_ref * (1.0 + fm::exp(t * (-1.0 / 20.0)) * ::sin(10.0 * t));
+  const double w = t * 1.5915494309189533577;  // 10 / (2 pi)
+  const double u = __builtin_fma(t, 1.5915494309189533577, -__builtin_floor(w));
+  double sn, cs;
+  fm::sincos2pi(u, sn, cs);
+  return K.V_ref * (1.0 + fm::exp(t * (-1.0 / 20.0)) * sn);
 }
 
 // slip rate and 1/theta at a point: what an incremental evaluation near that point starts from
@@ -34,239 +56,315 @@ struct Base {
   double v, rth;
 };
 
-// the derivative once v and 1/theta are known (RateStateModel.py:331-353)
-template <bool DAMP>
-__device__ __forceinline__ void friction_tail(const Consts &K, const LaneD &L, double vl, double v, double rth, double theta,
-                                              double f[3]) {
-  f[1] = 1.0 - v * theta * L.inv_dc;
-  f[0] = L.kprime * (vl - v);
-  const double bt = L.b * rth * f[1], va = v * L.inv_a;
-  f[2] = va * (f[0] - bt);
+// derivative of (mu, theta, V) at one point
+struct Deriv {
+  double m, t, v;
+};
+
+// the derivative once v and 1/theta are known (RateStateModel.py:331-353); WANT_V = false leaves d.v at the undamped
+// value where only the damping feedback needs it (stages whose V derivative enters no sum)
+template <bool DAMP, bool WANT_V>
+__device__ __forceinline__ Deriv friction_tail(const Consts &K, const LaneD &L, double vl, double v, double rth, double theta) {
+  Deriv d;
+  d.t = 1.0 - v * theta * L.inv_dc;
+  d.m = L.kprime * (vl - v);
+  const double bt = L.b * rth * d.t, va = v * L.inv_a;
+  d.v = va * (d.m - bt);
   if (DAMP) {
-    f[0] = f[0] - K.k1 * f[2];
-    f[2] = va * (f[0] - bt);
+    d.m = d.m - K.k1 * d.v;
+    if (WANT_V) d.v = va * (d.m - bt);
   }
+  return d;
 }
 
 // RateStateModel.py:318-355 given the loading velocity vl at the evaluation time
 template <bool DAMP>
-__device__ __forceinline__ void friction(const Consts &K, const LaneD &L, double vl, const double y[3], double f[3], Base &b) {
-  b.v = K.V_ref * fm::exp(L.inv_a * (y[0] - K.mu_ref - L.b * fm::log(K.V_ref * y[1] * L.inv_dc)));
-  b.rth = fm::rcp(y[1]);
-  friction_tail<DAMP>(K, L, vl, b.v, b.rth, y[1], f);
+__device__ __forceinline__ Deriv friction(const Consts &K, const LaneD &L, double vl, double mu, double theta, Base &b) {
+  b.v = K.V_ref * fm::exp(L.inv_a * (mu - K.mu_ref - L.b * fm::log(K.V_ref * theta * L.inv_dc)));
+  b.rth = fm::rcp(theta);
+  return friction_tail<DAMP, true>(K, L, vl, b.v, b.rth, theta);
 }
 
-template <bool DAMP>
-__device__ __forceinline__ void friction(const Consts &K, const LaneD &L, double vl, const double y[3], double f[3]) {
-  Base b;
-  friction<DAMP>(K, L, vl, y, f, b);
+// Largest |rho| / |dlt| of a step's incremental stages, tracked through the high words of the doubles read as floats
+// (monotone in |x|, power-of-two thresholds exact; rsf_device.h, struct Guard): one v_max_f32 per value instead of a
+// compare and a mask operation, and ONE test per step — a branch per stage would stall a lone wave for the latency of
+// its compare eleven times per step.
+struct GuardD {
+  float rho, dlt;
+};
+
+// The derivative at a point (mu + dmu, theta + dth) near a point whose slip rate / reciprocal state b0 are known:
+// v = b0.v exp(dlt), dlt = (dmu - b log1p(rho))/a, rho = dth/theta — by the series of rsf_device.h's TIGHT tier (log1p to
+// rho^2/2, expm1 to dlt^5/120, 1/theta = (1/theta_0)(1 + q), q = rho^2 - rho; truncation < 1e-17 relative), valid inside
+// |rho| < 2^-20, |dlt| < 2^-9.  A DOP853 step spans one output interval, so its stage increments are those of an RK4
+// step: the full log/exp is needed only where rounding must not accumulate (kResyncDp).  Outside the range the step's
+// guard trips and the step is taken again by the general loop of call(), every stage evaluated in full.
+//
+// FastStep holds what a step's twelve incremental evaluations share, so that a stage costs ~25 instructions instead of
+// ~30: with sm / sth the stage's tableau sums of the mu / theta derivatives,
+//     rho = (h/theta_0) sth        theta_s/Dc = theta_0/Dc + (h/Dc) sth        dlt = (h/a) sm - (b/a) log1p(rho),
+// and the bracket of dV/dt = (v/a)(dmu/dt - (b/theta) dtheta/dt), g = k'(V_l - v) - (b/theta_s)(1 - v theta_s/Dc), is LINEAR
+// in v once (1/theta_s)(theta_s/Dc) = 1/Dc is used:   g = (k' V_l - b/theta_s) + (b/Dc - k') v,   b/theta_s = (b/theta_0)(1 + q)
+// (b/theta_s and (b/Dc) v nearly cancel near steady state; against k' V_l their rounding is ~1e-17 of g — the same
+// regrouping as rsf_device.h's rhs_fast).  The damping pass (RateStateModel.py:349-353) subtracts the same k1 dV/dt from
+// dmu/dt and from g.
+struct FastStep {
+  double ha, hd, hr;   // h/a, h/Dc, h/theta_0
+  double thd0, br0;    // theta_0/Dc, b/theta_0
+};
+
+__device__ __forceinline__ FastStep fast_step(const LaneD &L, double h, double theta0, const Base &b0) {
+  FastStep F;
+  F.ha = h * L.inv_a; F.hd = h * L.inv_dc; F.hr = h * b0.rth;
+  F.thd0 = theta0 * L.inv_dc; F.br0 = L.b * b0.rth;
+  return F;
 }
 
-// The same derivative at a stage point ys = y + (dmu, dth, .) of a step whose start point has slip rate / reciprocal
-// state b0: v = b0.v exp(dlt), dlt = (dmu - b log1p(rho))/a, rho = dth/theta — by the series of rsf_device.h's NARROW
-// tier (log1p to rho^6/6, expm1 to dlt^7/5040, 1/theta by one Newton step; truncation < 1e-19), valid inside
-// |rho| < 2^-9, |dlt| < 2^-6.  Outside, `bad` is raised and the caller redoes the step's stages with full evaluations
-// — ONE test per step: a branch per stage would stall a lone wave for the latency of its compare eleven times per
-// step.  A DOP853 step spans one output interval, so its stage increments are those of an RK4 step: the full log/exp
-// is needed only at the step's end points.
-// SHORT: the series lengths and thresholds of rsf_device.h's TIGHT tier (log1p to rho^2/2 inside |rho| < 2^-20, expm1 to
-// dlt^5/120 inside |dlt| < 2^-9) — what the steady-state fast path of call() tries first.
-template <bool DAMP, bool SHORT>
-__device__ __forceinline__ void friction_incr(const Consts &K, const LaneD &L, double vl, const Base &b0, double dmu, double dth,
-                                              const double ys[3], double f[3], bool &bad) {
-  const double rho = dth * b0.rth;
-  double p;
-  if (SHORT) {
-    p = __builtin_fma(rho, -0.5, 1.0);
-  } else {
-    p = -1.0 / 6.0;
-    p = __builtin_fma(p, rho, 1.0 / 5.0);
-    p = __builtin_fma(p, rho, -1.0 / 4.0);
-    p = __builtin_fma(p, rho, 1.0 / 3.0);
-    p = __builtin_fma(p, rho, -0.5);
-    p = __builtin_fma(p, rho, 1.0);
-  }
-  const double dlt = L.inv_a * __builtin_fma(-L.b, p * rho, dmu);
-  bad = bad || !(__builtin_fabs(rho) < (SHORT ? 0x1.0p-20 : 0x1.0p-9) && __builtin_fabs(dlt) < (SHORT ? 0x1.0p-9 : 0x1.0p-6));
-  double e;
-  if (SHORT) {
-    e = 1.0 / 120.0;
-  } else {
-    e = 1.0 / 5040.0;
-    e = __builtin_fma(e, dlt, 1.0 / 720.0);
-    e = __builtin_fma(e, dlt, 1.0 / 120.0);
-  }
+template <bool DAMP, bool WANT_V>
+__device__ __forceinline__ Deriv friction_incr(const Consts &K, const LaneD &L, const FastStep &F, double vl, const Base &b0, double sm,
+                                               double sth, GuardD &g, Base *at_point = nullptr) {
+  const double rho = F.hr * sth;
+  g.rho = __builtin_fmaxf(g.rho, __builtin_fabsf(hi_as_float(rho)));
+  const double p = __builtin_fma(rho, -0.5, 1.0);
+  const double dlt = __builtin_fma(-L.boa, p * rho, F.ha * sm);
+  g.dlt = __builtin_fmaxf(g.dlt, __builtin_fabsf(hi_as_float(dlt)));
+  double e = 1.0 / 120.0;
   e = __builtin_fma(e, dlt, 1.0 / 24.0);
   e = __builtin_fma(e, dlt, 1.0 / 6.0);
   e = __builtin_fma(e, dlt, 0.5);
   e = __builtin_fma(e, dlt, 1.0);
   const double v = __builtin_fma(b0.v * dlt, e, b0.v);
-  double rth = __builtin_fma(b0.rth, __builtin_fma(rho, rho, -rho), b0.rth);
-  if (!SHORT) rth = __builtin_fma(rth, __builtin_fma(-ys[1], rth, 1.0), rth);  // (|rho| < 2^-20: the series is exact to rounding)
-  friction_tail<DAMP>(K, L, vl, v, rth, ys[1], f);
+  const double q = __builtin_fma(rho, rho, -rho);
+  if (at_point) { at_point->v = v; at_point->rth = __builtin_fma(b0.rth, q, b0.rth); }
+  const double kvl = L.kprime * vl;
+  Deriv d;
+  d.t = __builtin_fma(-v, __builtin_fma(F.hd, sth, F.thd0), 1.0);       // 1 - v theta_s / Dc
+  d.m = __builtin_fma(-L.kprime, v, kvl);                                // k' (V_l - v)
+  double gg = __builtin_fma(L.c3, v, __builtin_fma(-F.br0, q, kvl - F.br0));
+  const double va = v * L.inv_a;
+  d.v = va * gg;
+  if (DAMP) {
+    d.m = __builtin_fma(-K.k1, d.v, d.m);
+    if (WANT_V) d.v = va * __builtin_fma(-K.k1, d.v, gg);
+  }
+  return d;
+}
+
+__device__ __forceinline__ bool guard_tripped(const GuardD &g) {  // (NaN reads as a float NaN, which max ignores: a dead lane
+  return !(g.rho < hi_pow2(-20) && g.dlt < hi_pow2(-9));          //  ends in err = NaN and fails its call like the reference's)
 }
 
 template <bool DAMP>
-__device__ __forceinline__ double hinit(const Consts &K, const LaneD &L, double x, const double y[3], const double f0[3],
-                                        double hmax) {
-  double dnf = 0.0, dny = 0.0, y1[3], f1[3], der2 = 0.0;
+__device__ __forceinline__ double hinit(const Consts &K, const LaneD &L, double x, const double y[3], const Deriv &f0, double hmax) {
+  const double f0a[3] = {f0.m, f0.t, f0.v};
+  double dnf = 0.0, dny = 0.0, y1[3], der2 = 0.0;
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
     const double sk = kAtol + kRtol * fabs(y[i]);
-    dnf += (f0[i] / sk) * (f0[i] / sk);
+    dnf += (f0a[i] / sk) * (f0a[i] / sk);
     dny += (y[i] / sk) * (y[i] / sk);
   }
   double h = (dnf <= 1e-10 || dny <= 1e-10) ? 1.0e-6 : sqrt(dny / dnf) * 0.01;
   h = fmin(h, hmax);
 #pragma unroll
-  for (int i = 0; i < 3; ++i) y1[i] = y[i] + h * f0[i];
-  friction<DAMP>(K, L, loading(K, x + h), y1, f1);
+  for (int i = 0; i < 3; ++i) y1[i] = y[i] + h * f0a[i];
+  Base unused;
+  const Deriv f1 = friction<DAMP>(K, L, loading(K, x + h), y1[0], y1[1], unused);
+  const double f1a[3] = {f1.m, f1.t, f1.v};
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
     const double sk = kAtol + kRtol * fabs(y[i]);
-    der2 += ((f1[i] - f0[i]) / sk) * ((f1[i] - f0[i]) / sk);
+    der2 += ((f1a[i] - f0a[i]) / sk) * ((f1a[i] - f0a[i]) / sk);
   }
   der2 = sqrt(der2) / h;
   const double der12 = fmax(fabs(der2), sqrt(dnf));
-  const double h1 = der12 <= 1e-15 ? fmax(1.0e-6, fabs(h) * 1.0e-3) : pow(0.01 / der12, 1.0 / 8.0);
+  const double h1 = der12 <= 1e-15 ? fmax(1.0e-6, fabs(h) * 1.0e-3) : fm::exp(0.125 * fm::log(0.01 / der12));  // ** (1/8)
   return fmin(fmin(100.0 * fabs(h), h1), hmax);
 }
 
-// one dop853 call (forward in time): y from x to xend; hc = carried step size (0 => HINIT).  false on failure.
-// the eleven inner stages of one step of size h from (x, y, k[0]; b0), evaluated incrementally; `bad`: some increment
-// left the series' range (the values of that lane are then not to be used).  TABULATED = the fast path of call(): the
-// loading table and the short series.
-template <bool DAMP, bool TABULATED>
-__device__ __forceinline__ void stages_incr(const Consts &K, const LaneD &L, const double *tab, bool standard, double x, double h,
-                                            const double y[3], double (&k)[12][3], const Base &b0, bool &bad) {
+// the V component's share of a step's closing sums, accumulated stage by stage (see the header)
+struct VSums {
+  double s, e5;          // sum_j B_j k_j and sum_j E5_j k_j over the stages done so far
+  double k1, k9, k12;    // the three stage values the 3rd-order estimator subtracts (kBhh)
+};
+
+// The eleven inner stages of one step of size h from (x, y; first-stage derivative km[0], kt[0], vs.k1; b0).
+//   FAST   the tabulated standard step, stages evaluated incrementally (the steady state of call());
+//          → whether the lane's increments left the series' range (its values are then not to be used)
+//   !FAST  any step, every stage evaluated in full (`standard`: the loading table applies); → false
+// Both are straight-line code (eleven unrolled stages): that keeps the km / kt arrays in registers.  There is deliberately
+// no third, "incremental with longer series" variant for the general loop: the loop body would then hold two unrolled
+// stage blocks, and the sampler kernel no longer fits two waves per SIMD without spilling (measured: 128-364 B of
+// scratch per lane); the general loop runs for the first interval of a solve (HINIT), after a rejected step, and for
+// waves that hold a stiff small-Dc lane.
+template <bool DAMP, bool FAST>
+__device__ __forceinline__ bool stages(const Consts &K, const LaneD &L, const double *tab, bool standard, double x, double h,
+                                       const double y[3], double (&km)[12], double (&kt)[12], const Base &b0, VSums &vs) {
+  GuardD g = {0.0f, 0.0f};
+  const FastStep F = fast_step(L, h, y[1], b0);
+  vs.s = RSF_DP_B[0] * vs.k1;
+  vs.e5 = RSF_DP_E5[0] * vs.k1;
 #pragma unroll
   for (int st = 1; st < 12; ++st) {
-    double inc[3], ys[3];
+    double sm = 0.0, sth = 0.0;
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      double s = 0.0;
-#pragma unroll
-      for (int j = 0; j < st; ++j)
-        if (RSF_DP_A[st - 1][j] != 0.0) s += RSF_DP_A[st - 1][j] * k[j][i];
-      inc[i] = h * s;
-      ys[i] = y[i] + inc[i];
+    for (int j = 0; j < st; ++j)
+      if (RSF_DP_A[st - 1][j] != 0.0) {
+        sm += RSF_DP_A[st - 1][j] * km[j];
+        sth += RSF_DP_A[st - 1][j] * kt[j];
+      }
+    const double vl = (FAST || standard) ? tab[st] : loading(K, st == 11 ? x + h : x + RSF_DP_C[st] * h);
+    const bool want_v = st >= 5;  // stages 6..12 (1-based) carry weight in the closing sums
+    Deriv d;
+    if (!FAST) {
+      Base unused;
+      d = friction<DAMP>(K, L, vl, y[0] + h * sm, y[1] + h * sth, unused);
+    } else if (want_v) {
+      d = friction_incr<DAMP, true>(K, L, F, vl, b0, sm, sth, g);
+    } else {
+      d = friction_incr<DAMP, false>(K, L, F, vl, b0, sm, sth, g);
     }
-    const double vl = (TABULATED || standard) ? tab[st] : loading(K, st == 11 ? x + h : x + RSF_DP_C[st] * h);
-    friction_incr<DAMP, TABULATED>(K, L, vl, b0, inc[0], inc[1], ys, k[st], bad);
+    km[st] = d.m;
+    kt[st] = d.t;
+    if (want_v) {
+      vs.s = __builtin_fma(RSF_DP_B[st - 4], d.v, vs.s);
+      vs.e5 = __builtin_fma(RSF_DP_E5[st - 4], d.v, vs.e5);
+    }
+    if (st == 8) vs.k9 = d.v;
+    if (st == 11) vs.k12 = d.v;
   }
+  return FAST && guard_tripped(g);
 }
 
-// 8th-order solution k5 and the error estimate of the step; returns err, and err ** (1/8) in fac11
-__device__ __forceinline__ double solution_and_error(double h, const double y[3], const double (&k)[12][3], double k5[3],
-                                                     double &fac11) {
+// 8th-order solution k5 and the error estimate of the step; returns err, and err ** (1/8) in fac11.
+// The solution is formed as the reference forms it.  The error norm and the step-size factor steer h and the accept test
+// err <= 1:
+//   !APPROX (general loop): reciprocals, square root and err ** (1/8) to ~1 ulp (rsf_math.h) — where the controller
+//           really chooses step sizes (HINIT's first interval, stiff small-Dc lanes: thousands of steps whose sizes
+//           feed back into the solution at the level of the tolerance), the step sequence has to be the reference's;
+//   APPROX  (fast path): the step IS the output interval whatever the controller says, and the carried prediction is
+//           only compared with it (x + 1.01 h > xend), so the hardware's approximate reciprocal / reciprocal square root /
+//           square root (v_rcp_f64, v_rsq_f64, v_sqrt_f64: ~1e-7 relative, one instruction each) stand in for dop853.f's
+//           divisions, sqrt and pow: err ** (1/8) is three square roots.  A prediction that ends the steady state enters the
+//           general loop as a step size 1e-7 off — a perturbation of the solution ~1e-7 times a local error.
+template <bool APPROX>
+__device__ __forceinline__ double solution_and_error(double h, const double y[3], const double (&km)[12], const double (&kt)[12],
+                                                     const VSums &vs, double k5[3], double &fac11, double (&s)[3]) {
+  double e5[3] = {0.0, 0.0, vs.e5}, e3[3];
+  s[0] = 0.0; s[1] = 0.0; s[2] = vs.s;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    s[0] += RSF_DP_B[j] * km[RSF_DP_W_STAGE[j]];
+    s[1] += RSF_DP_B[j] * kt[RSF_DP_W_STAGE[j]];
+    e5[0] += RSF_DP_E5[j] * km[RSF_DP_W_STAGE[j]];
+    e5[1] += RSF_DP_E5[j] * kt[RSF_DP_W_STAGE[j]];
+  }
+  e3[0] = s[0] - kBhh1 * km[0] - kBhh2 * km[8] - kBhh3 * km[11];
+  e3[1] = s[1] - kBhh1 * kt[0] - kBhh2 * kt[8] - kBhh3 * kt[11];
+  e3[2] = s[2] - kBhh1 * vs.k1 - kBhh2 * vs.k9 - kBhh3 * vs.k12;
   double err = 0.0, err2 = 0.0;
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
-    double s = 0.0, e3 = 0.0, e5 = 0.0;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const double kj = k[RSF_DP_W_STAGE[j]][i];
-      s += RSF_DP_B[j] * kj;
-      e3 += RSF_DP_E3[j] * kj;
-      e5 += RSF_DP_E5[j] * kj;
-    }
-    k5[i] = y[i] + h * s;
-    // Step-size control: the error norm and the step-size factor only steer h (and the accept test err <= 1), so
-    // they use the kernel's reciprocal / log / exp (<= 4 ulp from the divisions and pow of the Fortran code, a fifth
-    // of their instructions); the solution itself (k5) is formed exactly as the reference forms it.
-    const double isk = fm::rcp(kAtol + kRtol * fmax(fabs(y[i]), fabs(k5[i])));
-    err2 += (e3 * isk) * (e3 * isk);
-    err += (e5 * isk) * (e5 * isk);
+    k5[i] = y[i] + h * s[i];
+    const double sk = kAtol + kRtol * fmax(fabs(y[i]), fabs(k5[i]));
+    const double isk = APPROX ? __builtin_amdgcn_rcp(sk) : fm::rcp(sk);
+    err2 += (e3[i] * isk) * (e3[i] * isk);
+    err += (e5[i] * isk) * (e5[i] * isk);
   }
   double deno = err + 0.01 * err2;
   if (deno <= 0.0) deno = 1.0;
-  err = fabs(h) * err * sqrt(fm::rcp(3.0 * deno));
-  fac11 = err > 0.0 ? fm::exp(0.125 * fm::log(err)) : (err == 0.0 ? 0.0 : err);  // err ** (1/8); NaN stays NaN
+  if (APPROX) {
+    err = fabs(h) * err * __builtin_amdgcn_rsq(3.0 * deno);
+    fac11 = __builtin_amdgcn_sqrt(__builtin_amdgcn_sqrt(__builtin_amdgcn_sqrt(err)));  // 0 stays 0, NaN stays NaN
+  } else {
+    err = fabs(h) * err * sqrt(fm::rcp(3.0 * deno));
+    fac11 = err > 0.0 ? fm::exp(0.125 * fm::log(err)) : (err == 0.0 ? 0.0 : err);  // err ** (1/8); NaN stays NaN
+  }
   return err;
 }
 
+// What a call hands to the next one: the carried step size (0 => HINIT), and the derivative and (v, 1/theta) at (x, y)
+// — every call starts by evaluating the RHS at its start point (SciPy does), which is the point and, for the tabulated
+// standard step, bit for bit the value at which the previous call's last accepted step ended (first-same-as-last).
+struct Carry {
+  double hc;
+  Deriv kf;
+  Base bf;
+  bool have_kf;
+};
+
+// In the steady state even the derivative at the step's END point — the next step's first stage — is reached
+// incrementally from the step's start point (the same series as the inner stages: the whole step's increments are inside
+// their range, as in the RK4 path's TIGHT tier).  (v, 1/theta) then pass from step to step by multiplicative updates;
+// every kResyncDp-th interval of a chunk the end point is evaluated in full, so rounding cannot accumulate.
+constexpr int kResyncDp = 64;
+
+// one dop853 call (forward in time): y from x to xend.  false on failure.
 // `tab` (LDS, 12 values) holds V_l at the stage times of the STANDARD step of this interval — the first step
 // clipped to h = xend - x, which is what every call after the first interval takes; x and xend are the
 // accumulated grid times shared by all lanes, so the host can tabulate them bit-exactly (rsf_set_model).
 // Any other step (HINIT's first interval, steps after a rejection) evaluates V_l(t) directly.
-// `kf` carries the derivative at (x, y) from call to call: every call starts by evaluating the RHS at its start point
-// (SciPy does), which is the point — and, for the tabulated standard step, bit for bit the value — at which the
-// previous call's last accepted step ended (first-same-as-last); have_kf = false on the first call.
 template <bool DAMP>
-__device__ __forceinline__ bool call(const Consts &K, const LaneD &L, const double *tab, double &x, double xend, double y[3],
-                                     double &hc, double kf[3], Base &bf, bool &have_kf) {
+__device__ __forceinline__ bool call(const Consts &K, const LaneD &L, const double *tab, double &x, double xend, double y[3], Carry &c,
+                                     bool resync) {  // resync: wave-uniform
   constexpr double safe = 0.9, facc1 = 1.0 / 0.3, facc2 = 1.0 / 6.0, uround = 2.3e-16;
   const double hmax = fabs(xend - x);
-  double k[12][3], ys[3], k5[3];
-  double h = hc;
+  double km[12], kt[12], k5[3], ssum[3];
+  VSums vs;
+  double h = c.hc;
   bool last = false, reject = false;
-  Base b0 = bf;  // slip rate and 1/theta at (x, y): the stages of a step are evaluated incrementally from it
-  if (have_kf) {
-#pragma unroll
-    for (int i = 0; i < 3; ++i) k[0][i] = kf[i];
-  } else {
-    friction<DAMP>(K, L, tab[0], y, k[0], b0);  // V_l(x): x is the interval's start time for every lane
-  }
-  if (h == 0.0) h = hinit<DAMP>(K, L, x, y, k[0], hmax);
+  Base b0 = c.bf;  // slip rate and 1/theta at (x, y): the stages of a step are evaluated incrementally from it
+  Deriv k1 = c.kf;
+  if (!c.have_kf) k1 = friction<DAMP>(K, L, tab[0], y[0], y[1], b0);  // V_l(x): x is the interval's start time for every lane
+  if (h == 0.0) h = hinit<DAMP>(K, L, x, y, k1, hmax);
   // Fast path, the steady state of every call after the first interval: the carried step size reaches past xend for
   // EVERY lane of the wave, so all take the tabulated step h = xend - x, and all accept it.  Two wave-uniform tests
   // instead of the general loop's six per-lane branches (each of which a lone wave sits out for the latency of its
   // compare).  Anything else — a lane that wants a smaller step, leaves the series' range or rejects — falls through
-  // to the general loop, which starts again from the untouched (x, y, k[0]).
-  if (__all(have_kf && (x + 1.01 * h - xend > 0.0) && !(0.1 * fabs(h) <= fabs(x) * uround))) {
+  // to the general loop, which starts again from the untouched (x, y, k1).
+  if (__all(c.have_kf && (x + 1.01 * h - xend > 0.0) && !(0.1 * fabs(h) <= fabs(x) * uround))) {
     const double hs = xend - x;
-    bool bad = false;
     double fac11;
-    stages_incr<DAMP, true>(K, L, tab, true, x, hs, y, k, b0, bad);
-    const double err = solution_and_error(hs, y, k, k5, fac11);
+    km[0] = k1.m; kt[0] = k1.t; vs.k1 = k1.v;
+    const bool bad = stages<DAMP, true>(K, L, tab, true, x, hs, y, km, kt, b0, vs);
+    const double err = solution_and_error<true>(hs, y, km, kt, vs, k5, fac11, ssum);
     if (__all(!bad && err <= 1.0)) {
-      friction<DAMP>(K, L, tab[11], k5, kf, bf);  // first-same-as-last, at xend: full evaluation
+      // first-same-as-last, at xend
+      bool full = resync;
+      if (!full) {
+        GuardD g = {0.0f, 0.0f};
+        c.kf = friction_incr<DAMP, true>(K, L, fast_step(L, hs, y[1], b0), tab[11], b0, ssum[0], ssum[1], g, &c.bf);
+        full = __any(guard_tripped(g));
+      }
+      if (full) c.kf = friction<DAMP>(K, L, tab[11], k5[0], k5[1], c.bf);
 #pragma unroll
       for (int i = 0; i < 3; ++i) y[i] = k5[i];
       x = x + hs;
-      hc = hs * fm::rcp(fmax(facc2, fmin(facc1, fac11 * (1.0 / safe))));
+      c.hc = hs * fm::rcp(fmax(facc2, fmin(facc1, fac11 * (1.0 / safe))));
       return true;
     }
   }
-  for (int nstep = 0;; ) {
+  for (int nstep = 0;;) {
     if (nstep > 500) return false;
     if (0.1 * fabs(h) <= fabs(x) * uround) return false;
     if (x + 1.01 * h - xend > 0.0) { h = xend - x; last = true; }
     const bool standard = last && nstep == 0;  // the tabulated step
     ++nstep;
-    bool bad = false;
-    stages_incr<DAMP, false>(K, L, tab, standard, x, h, y, k, b0, bad);
-    if (__builtin_expect(__any(bad), 0)) {  // an increment outside the series' range: this step again, every stage in full
-      if (bad) {
-#pragma unroll
-        for (int st = 1; st < 12; ++st) {
-#pragma unroll
-          for (int i = 0; i < 3; ++i) {
-            double s = 0.0;
-#pragma unroll
-            for (int j = 0; j < st; ++j)
-              if (RSF_DP_A[st - 1][j] != 0.0) s += RSF_DP_A[st - 1][j] * k[j][i];
-            ys[i] = y[i] + h * s;
-          }
-          const double vl = standard ? tab[st] : loading(K, st == 11 ? x + h : x + RSF_DP_C[st] * h);
-          friction<DAMP>(K, L, vl, ys, k[st]);
-        }
-      }
-    }
+    km[0] = k1.m; kt[0] = k1.t; vs.k1 = k1.v;
+    stages<DAMP, false>(K, L, tab, standard, x, h, y, km, kt, b0, vs);
     double fac11;
-    const double err = solution_and_error(h, y, k, k5, fac11);
+    const double err = solution_and_error<false>(h, y, km, kt, vs, k5, fac11, ssum);
     double hnew = h * fm::rcp(fmax(facc2, fmin(facc1, fac11 * (1.0 / safe))));
     if (err <= 1.0) {
-      friction<DAMP>(K, L, standard ? tab[11] : loading(K, x + h), k5, k[0], b0);  // first-same-as-last, at x + h: full
+      k1 = friction<DAMP>(K, L, standard ? tab[11] : loading(K, x + h), k5[0], k5[1], b0);  // first-same-as-last, at x + h: full
 #pragma unroll
       for (int i = 0; i < 3; ++i) y[i] = k5[i];
       x = x + h;
       if (last) {
-        hc = hnew;
-#pragma unroll
-        for (int i = 0; i < 3; ++i) kf[i] = k[0][i];
-        bf = b0;
-        have_kf = true;
+        c.hc = hnew;
+        c.kf = k1;
+        c.bf = b0;
+        c.have_kf = true;
         return true;
       }
       if (fabs(hnew) > hmax) hnew = hmax;
@@ -295,18 +393,30 @@ __device__ __forceinline__ void stage_chunk_dp(double *lds, const Consts &K, int
   __syncthreads();
 }
 
+__device__ __forceinline__ LaneD make_lane_dp(double dc, double a, double b) {
+  LaneD L;
+  L.inv_dc = 1.0 / dc; L.kprime = (1e-2 * 10) / dc; L.inv_a = 1.0 / a; L.b = b;
+  L.boa = b * L.inv_a; L.c3 = b * L.inv_dc - L.kprime;
+  return L;
+}
+
+__device__ __forceinline__ Carry fresh_carry() {
+  Carry c;
+  c.hc = 0.0; c.kf = {0.0, 0.0, 0.0}; c.bf = {0.0, 0.0}; c.have_kf = false;
+  return c;
+}
+
 // Forward solve in the reference's scheme.  Same calling convention as rsf::solve (all threads call it; the
 // loading table and the observation are read from the LDS chunk staged by stage_chunk_dp).
 template <bool DAMP, bool WANT_SSQ, bool WANT_ACC>
 __device__ __forceinline__ double solve(double *lds, const Consts &K, bool resident, bool active, double dc, double a,
                                         double b, double *acc_out, int64_t stride) {
-  LaneD L;
-  L.inv_dc = 1.0 / dc; L.kprime = (1e-2 * 10) / dc; L.inv_a = 1.0 / a; L.b = b;
+  const LaneD L = make_lane_dp(dc, a, b);
   const double delta_t = K.dt, inv_dt = K.inv_dt;
   double y[3] = {K.mu0, dc / K.V_ref, K.V_ref};
-  double x = K.t0, vprev = K.V_ref, hc = 0.0, ssq = 0.0, kf[3] = {0.0, 0.0, 0.0};
-  Base bf = {0.0, 0.0};
-  bool failed = false, have_kf = false;
+  double x = K.t0, vprev = K.V_ref, ssq = 0.0;
+  Carry c = fresh_carry();
+  bool failed = false;
   if (WANT_SSQ && active) { const double d0 = K.data[0]; ssq = d0 * d0; }
   if (WANT_ACC && active) acc_out[0] = 0.0;
   const double *ld = lds + lds_data_offset_dp(K);
@@ -317,7 +427,7 @@ __device__ __forceinline__ double solve(double *lds, const Consts &K, bool resid
     for (int kk = 0; kk < kn; ++kk) {
       double ak = 0.0;  // after a failed call the reference's arrays keep their zeros (RateStateModel.py:361-381)
       if (!failed) {
-        failed = !call<DAMP>(K, L, lds + kTab * kk, x, x + delta_t, y, hc, kf, bf, have_kf);
+        failed = !call<DAMP>(K, L, lds + kTab * kk, x, x + delta_t, y, c, (kk & (kResyncDp - 1)) == kResyncDp - 1);
         ak = (y[2] - vprev) * inv_dt;
         vprev = y[2];
       }

@@ -246,10 +246,9 @@ __global__ void __launch_bounds__(kMaxBlock) init_dp_kernel(Consts K, InitArgs A
     if (D == 3) { p0[1] = A.q0[A.C + i]; p0[2] = A.q0[2 * A.C + i]; }
   }
   rsf::dp::LaneD L[D + 1];
-  double y[D + 1][3], x[D + 1], hc[D + 1], vprev[D + 1], inv_den[D];
-  bool failed[D + 1], have_kf[D + 1];
-  double kfs[D + 1][3];
-  rsf::dp::Base bfs[D + 1];
+  rsf::dp::Carry cw[D + 1];
+  double y[D + 1][3], x[D + 1], vprev[D + 1], inv_den[D];
+  bool failed[D + 1];
 #pragma unroll
   for (int t = 0; t <= D; ++t) {
     double pq[3] = {p0[0], p0[1], p0[2]};
@@ -257,9 +256,10 @@ __global__ void __launch_bounds__(kMaxBlock) init_dp_kernel(Consts K, InitArgs A
       pq[t - 1] = pq[t - 1] * (1 + A.fd);
       inv_den[t - 1] = 1.0 / (pq[t - 1] * A.fd);  // perturbed value in the denominator, MCMC.py:264
     }
-    L[t].inv_dc = 1.0 / pq[0]; L[t].kprime = (1e-2 * 10) / pq[0]; L[t].inv_a = 1.0 / pq[1]; L[t].b = pq[2];
+    L[t] = rsf::dp::make_lane_dp(pq[0], pq[1], pq[2]);
+    cw[t] = rsf::dp::fresh_carry();
     y[t][0] = K.mu0; y[t][1] = pq[0] / K.V_ref; y[t][2] = K.V_ref;
-    x[t] = K.t0; hc[t] = 0.0; vprev[t] = K.V_ref; failed[t] = false; have_kf[t] = false;
+    x[t] = K.t0; vprev[t] = K.V_ref; failed[t] = false;
   }
   double xtx[D * D];
 #pragma unroll
@@ -278,7 +278,7 @@ __global__ void __launch_bounds__(kMaxBlock) init_dp_kernel(Consts K, InitArgs A
       for (int t = 0; t <= D; ++t) {
         ak[t] = 0.0;
         if (!failed[t]) {
-          failed[t] = !rsf::dp::call<DAMP>(K, L[t], lds + rsf::dp::kTab * kk, x[t], x[t] + delta_t, y[t], hc[t], kfs[t], bfs[t], have_kf[t]);
+          failed[t] = !rsf::dp::call<DAMP>(K, L[t], lds + rsf::dp::kTab * kk, x[t], x[t] + delta_t, y[t], cw[t], true);
           ak[t] = (y[t][2] - vprev[t]) * K.inv_dt;
           vprev[t] = y[t][2];
         }
@@ -624,12 +624,14 @@ pool_moments_kernel(int64_t n, const double *__restrict__ x, int64_t stride, dou
 // (ds_add_u32), then adds its non-empty bins to the global 64-bit counters — integer atomics, so the result does not
 // depend on the order of arrival.  The bin of a sample is numpy.histogram's, edge cases included: a first guess
 // floor((x - lo) * nbins/(hi - lo)), then numpy's own correction against the bin EDGES np.linspace(lo, hi, nbins + 1)
-// (edge b = b * step + lo, two roundings — formed here with explicitly unfused multiply and add), so that a sample
+// (edge b = b * step + lo, two roundings — formed here with contraction switched off), so that a sample
 // sitting exactly on an edge — a chain that rejects repeats values like q0 — lands where numpy puts it.
 constexpr int kHistMaxBins = 4096;
 
 __device__ __forceinline__ double hist_edge(int b, double lo, double hi, double step, int nbins) {
-  return b == nbins ? hi : __dadd_rn(__dmul_rn((double)b, step), lo);
+#pragma clang fp contract(off)  // numpy's edge is a product rounded, then a sum rounded: no fused multiply-add here
+  const double m = (double)b * step;
+  return b == nbins ? hi : m + lo;
 }
 
 __device__ __forceinline__ int hist_bin(double v, double lo, double hi, double scale, double step, int nbins) {
