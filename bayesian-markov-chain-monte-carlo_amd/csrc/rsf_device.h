@@ -416,7 +416,11 @@ __device__ __forceinline__ bool trip_fast(const double *v, const Lane &L, const 
 template <bool DAMP, int NU>
 __device__ __forceinline__ void trip_cold(const double *v, const Lane &L, const Consts &K, State &s, double (&dv)[NU]) {
 #pragma unroll 1
-  for (int j = 0; j < NU; ++j) dv[j] = rk4_cold<DAMP>(s, v[2 * j], v[2 * j + 1], v[2 * j + 2], L, K);
+  for (int j = 0; j < NU; ++j) {  // one copy of the cold step; its result goes to dv[j] by selects, so that dv stays in registers
+    const double r = rk4_cold<DAMP>(s, v[2 * j], v[2 * j + 1], v[2 * j + 2], L, K);
+#pragma unroll
+    for (int m = 0; m < NU; ++m) dv[m] = m == j ? r : dv[m];
+  }
   eval_full(s.ms, s.x, L, K, s.w, s.rx);
 }
 

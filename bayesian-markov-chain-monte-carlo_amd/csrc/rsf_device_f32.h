@@ -8,7 +8,9 @@
 // 2^x, v_rcp_f32; ~1 ulp), so every RK4 stage is evaluated in full — no incremental series — and
 // the constants are pre-scaled for base 2.  The acceleration sample is formed from the step's
 // velocity INCREMENT, not from the difference of two velocities near V_ref, which would lose
-// ~4 digits in float32.  Same rescaled state as the float64 path: ms = mu/k', x = V_ref theta/Dc.
+// ~4 digits in float32.  Same rescaled state as the float64 path — ms = mu/k', x = V_ref theta/Dc — and the same
+// regrouping of the RHS around w = v/V_ref with dV/dt in units of vk (rsf_device.h, rhs_fast); the two state components
+// and their derivatives are carried as packed pairs (v_pk_fma_f32).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -18,58 +20,75 @@
 namespace rsf {
 namespace f32 {
 
+// two floats in one 64-bit register pair: (d(ms)/dt, d(x)/dt) of a stage travel together, so that the stage inputs, the
+// RK4 combination and the damping correction are v_pk_fma_f32 / v_pk_mul_f32 — one instruction for both components
+typedef float float2v __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ float2v pk_fma(float2v a, float2v b, float2v c) { return __builtin_elementwise_fma(a, b, c); }
+
 struct Lane32 {
   float kia2;    // (k'/a) log2(e)
   float tc2;     // -(mu_ref/a) log2(e)
   float boa;     // b/a
-  float kprime, k1k, via, bdc;
-  float hh, h, h6, hhd, hd, h6d, vref;
+  float beta;    // (V_ref b/Dc)/k' = 10 b V_ref: b/theta dtheta/dt in units of k' (rsf_device.h, struct Lane)
+  float c3;      // beta - V_ref
+  float kvk;     // (k1/k') vk = k1 V_ref/a: radiation damping
+  float vref;
+  float cv;      // (h/6)/delta_t * vk: acceleration sample = cv * (weighted sum of w g over the interval's steps)
+  float2v chh, ch, ch6;  // (h/2, (h/2) V_ref/Dc), (h, h V_ref/Dc), (h/6, (h/6) V_ref/Dc): step fractions of (ms, x)
 };
 
 __device__ __forceinline__ Lane32 make_lane32(double dc, double a, double b, const Consts &K) {
   const double log2e = 1.4426950408889634074;
   const double inv_a = 1.0 / a, inv_dc = 1.0 / dc, kprime = (1e-2 * 10) / dc;
+  const double vdc = K.V_ref * inv_dc;  // dx/dt = (V_ref/Dc) (1 - w x)
   Lane32 L;
   L.kia2 = (float)(kprime * inv_a * log2e);
   L.tc2 = (float)(-K.mu_ref * inv_a * log2e);
   L.boa = (float)(b * inv_a);
-  L.kprime = (float)kprime;
-  L.k1k = (float)(K.k1 / kprime);
-  L.via = (float)(K.V_ref * inv_a);
-  L.bdc = (float)(b * K.V_ref * inv_dc);
-  L.hh = (float)K.hh; L.h = (float)K.h; L.h6 = (float)K.h6;
-  const double vdc = K.V_ref * inv_dc;  // dx/dt = (V_ref/Dc) (1 - w x)
-  L.hhd = (float)(K.hh * vdc); L.hd = (float)(K.h * vdc); L.h6d = (float)(K.h6 * vdc);
+  L.beta = (float)(b * K.V_ref * (1.0 / (1e-2 * 10)));
+  L.c3 = (float)(b * K.V_ref * (1.0 / (1e-2 * 10)) - K.V_ref);
+  L.kvk = (float)(K.k1 * K.V_ref * inv_a);
   L.vref = (float)K.V_ref;
+  L.cv = (float)(K.cacc * (K.V_ref * inv_a * kprime));
+  L.chh = float2v{(float)K.hh, (float)(K.hh * vdc)};
+  L.ch = float2v{(float)K.h, (float)(K.h * vdc)};
+  L.ch6 = float2v{(float)K.h6, (float)(K.h6 * vdc)};
   return L;
 }
 
+// The RHS at (ms, x) = s, RateStateModel.py:318-355 in the float64 path's regrouping (rsf_device.h, rhs_fast): with
+// w = v/V_ref = 2^(kia2 ms + tc2 - (b/a) log2 x) the bracket of dV/dt = vk w g is linear in w,
+//     g = (V_l - beta/x) + (beta - V_ref) w,
+// and the damping pass (RateStateModel.py:349-353) subtracts the same (kvk w) g from d(ms)/dt and from g.
+// → d = (d(ms)/dt, dtheta/dt) and w g, the stage's dV/dt in units of vk.
 template <bool DAMP>
-__device__ __forceinline__ void rhs32(float ms, float x, float vl, const Lane32 &L, float &d0, float &d1, float &d2) {
-  const float w = __builtin_amdgcn_exp2f(__builtin_fmaf(-L.boa, __builtin_amdgcn_logf(x), __builtin_fmaf(ms, L.kia2, L.tc2)));
-  const float rx = __builtin_amdgcn_rcpf(x);
-  d1 = __builtin_fmaf(-w, x, 1.0f);
-  d0 = __builtin_fmaf(-L.vref, w, vl);
-  const float bt = (L.bdc * d1) * rx;
-  const float va = w * L.via;
-  d2 = va * __builtin_fmaf(L.kprime, d0, -bt);
+__device__ __forceinline__ float rhs32(float2v s, float vl, const Lane32 &L, float2v &d) {
+  const float lg = __builtin_amdgcn_logf(s.y), rx = __builtin_amdgcn_rcpf(s.y);
+  const float w = __builtin_amdgcn_exp2f(__builtin_fmaf(-L.boa, lg, __builtin_fmaf(s.x, L.kia2, L.tc2)));
+  const float t1 = __builtin_fmaf(-L.beta, rx, vl);
+  d.x = __builtin_fmaf(-L.vref, w, vl);   // V_l - v
+  d.y = __builtin_fmaf(-w, s.y, 1.0f);    // 1 - w x   (the two halves of one register pair: no move to form the pair)
+  float g = __builtin_fmaf(L.c3, w, t1);
   if (DAMP) {
-    d0 = __builtin_fmaf(-L.k1k, d2, d0);
-    d2 = va * __builtin_fmaf(L.kprime, d0, -bt);
+    const float kw = L.kvk * w;
+    d.x = __builtin_fmaf(-kw, g, d.x);
+    g = __builtin_fmaf(-kw, g, g);
   }
+  return w * g;
 }
 
-// one RK4 step; returns the velocity increment of the step
+// one RK4 step; returns the weighted sum k1 + 2 k2 + 2 k3 + k4 of dV/dt in units of vk
 template <bool DAMP>
-__device__ __forceinline__ float rk4_step32(float &ms, float &x, float vl0, float vlm, float vl1, const Lane32 &L) {
-  float a0, a1, a2, b0, b1, b2, c0, c1, c2, e0, e1, e2;
-  rhs32<DAMP>(ms, x, vl0, L, a0, a1, a2);
-  rhs32<DAMP>(__builtin_fmaf(L.hh, a0, ms), __builtin_fmaf(L.hhd, a1, x), vlm, L, b0, b1, b2);
-  rhs32<DAMP>(__builtin_fmaf(L.hh, b0, ms), __builtin_fmaf(L.hhd, b1, x), vlm, L, c0, c1, c2);
-  rhs32<DAMP>(__builtin_fmaf(L.h, c0, ms), __builtin_fmaf(L.hd, c1, x), vl1, L, e0, e1, e2);
-  ms = __builtin_fmaf(L.h6, a0 + 2.0f * b0 + 2.0f * c0 + e0, ms);
-  x = __builtin_fmaf(L.h6d, a1 + 2.0f * b1 + 2.0f * c1 + e1, x);
-  return L.h6 * (a2 + 2.0f * b2 + 2.0f * c2 + e2);
+__device__ __forceinline__ float rk4_step32(float2v &s, float vl0, float vlm, float vl1, const Lane32 &L) {
+  float2v a, b, c, e;
+  const float wa = rhs32<DAMP>(s, vl0, L, a);
+  const float wb = rhs32<DAMP>(pk_fma(L.chh, a, s), vlm, L, b);
+  const float wc = rhs32<DAMP>(pk_fma(L.chh, b, s), vlm, L, c);
+  const float we = rhs32<DAMP>(pk_fma(L.ch, c, s), vl1, L, e);
+  const float2v two = {2.0f, 2.0f};
+  s = pk_fma(L.ch6, pk_fma(two, b + c, a + e), s);
+  return __builtin_fmaf(2.0f, wb + wc, wa + we);
 }
 
 // LDS layout (floats): [ vl : 2*S*kc+1 ][ data : kc ]; all threads of the workgroup must call it.
@@ -87,21 +106,41 @@ __device__ __forceinline__ void stage_chunk32(float *lds, const Consts &K, int k
   __syncthreads();
 }
 
-template <bool DAMP, bool WANT_SSQ, bool WANT_ACC>
+// S1: one step per output sample (the BASELINE configs) — the sample loop is then unrolled eight-fold into straight-line
+// code with the eight observations read ahead of the arithmetic, so that loop control, LDS addressing and the LDS
+// latency are paid once per eight steps (the float64 path's trip structure; a wave with one or two resident peers
+// cannot hide them otherwise).
+template <bool DAMP, bool WANT_SSQ, bool WANT_ACC, bool S1>
 __device__ __forceinline__ void integrate_chunk32(const float *lds, const Consts &K, const Lane32 &L, int k0, int kn,
-                                                  float &ms, float &x, double &ssq, double *acc_out, int64_t stride) {
+                                                  float2v &st, double &ssq, double *acc_out, int64_t stride) {
   const float *ld = lds + lds_data_offset32(K);
-  const float inv_dt = (float)K.inv_dt;
-  int j = 0;
-  for (int kk = 0; kk < kn; ++kk) {
-    float dv = 0.0f;
-    for (int sub = 0; sub < K.S; ++sub, j += 2) dv += rk4_step32<DAMP>(ms, x, lds[j], lds[j + 1], lds[j + 2], L);
-    const float ak = dv * inv_dt;  // RateStateModel.py:388, from the increment
+  auto emit = [&](int kk, float dv, float obs) {
+    const float ak = dv * L.cv;  // RateStateModel.py:388, from the interval's velocity increment
     if (WANT_ACC) acc_out[(int64_t)(k0 + kk) * stride] = (double)ak;
     if (WANT_SSQ) {
-      const double r = (double)(ak - ld[kk]);
+      const double r = (double)(ak - obs);
       ssq = __builtin_fma(r, r, ssq);
     }
+  };
+  int kk = 0;
+  if (S1) {
+    constexpr int NU = 8;
+    for (; kk + NU <= kn; kk += NU) {
+      const float *v = lds + 2 * kk;
+      float obs[NU], dv[NU];
+#pragma unroll
+      for (int j = 0; j < NU; ++j) obs[j] = WANT_SSQ ? ld[kk + j] : 0.0f;
+#pragma unroll
+      for (int j = 0; j < NU; ++j) dv[j] = rk4_step32<DAMP>(st, v[2 * j], v[2 * j + 1], v[2 * j + 2], L);
+#pragma unroll
+      for (int j = 0; j < NU; ++j) emit(kk + j, dv[j], obs[j]);
+    }
+  }
+  int j = 2 * K.S * kk;
+  for (; kk < kn; ++kk) {
+    float dv = 0.0f;
+    for (int sub = 0; sub < K.S; ++sub, j += 2) dv += rk4_step32<DAMP>(st, lds[j], lds[j + 1], lds[j + 2], L);
+    emit(kk, dv, WANT_SSQ ? ld[kk] : 0.0f);
   }
 }
 
@@ -109,7 +148,7 @@ template <bool DAMP, bool WANT_SSQ, bool WANT_ACC>
 __device__ __forceinline__ double solve32(float *lds, const Consts &K, bool resident, bool active, double dc, double a,
                                           double b, double *acc_out, int64_t stride) {
   const Lane32 L = make_lane32(dc, a, b, K);
-  float ms = (float)(K.mu0 / ((1e-2 * 10) / dc)), x = 1.0f;  // x = V_ref theta(0)/Dc, theta(0) = Dc/V_ref
+  float2v st = {(float)(K.mu0 / ((1e-2 * 10) / dc)), 1.0f};  // (ms, x); x = V_ref theta(0)/Dc = 1 with theta(0) = Dc/V_ref
   double ssq = 0.0;
   if (WANT_SSQ && active) {
     const double d0 = (double)(float)K.data[0];
@@ -119,7 +158,10 @@ __device__ __forceinline__ double solve32(float *lds, const Consts &K, bool resi
   for (int k0 = 1; k0 < K.nout; k0 += K.kc) {
     const int kn = min(K.kc, K.nout - k0);
     if (!resident) stage_chunk32(lds, K, k0, kn);
-    if (active) integrate_chunk32<DAMP, WANT_SSQ, WANT_ACC>(lds, K, L, k0, kn, ms, x, ssq, acc_out, stride);
+    if (active) {
+      if (K.S == 1) integrate_chunk32<DAMP, WANT_SSQ, WANT_ACC, true>(lds, K, L, k0, kn, st, ssq, acc_out, stride);
+      else integrate_chunk32<DAMP, WANT_SSQ, WANT_ACC, false>(lds, K, L, k0, kn, st, ssq, acc_out, stride);
+    }
   }
   return ssq;
 }

@@ -341,8 +341,15 @@ template <int D, bool DAMP, bool REPLAY, int MODE>
 __global__ void __launch_bounds__(kMaxBlock, kMinBlocks) mcmc_kernel(Consts K, McmcArgs A) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   rsf::select_group(K);
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  // Per-chain arrays are addressed as (wave-uniform row pointer)[threadIdx.x]: the row pointer — array + element * C + the
+  // workgroup's first chain — is scalar arithmetic, and the lane's share is one small 32-bit offset, so no access keeps a
+  // 64-bit per-lane address alive across the forward solve (with plain [e * C + i] indexing the compiler hoisted two dozen
+  // of them out of the iteration loop: 224 B of scratch per lane in the three-parameter kernel).
+  const int64_t blk = (int64_t)blockIdx.x * blockDim.x;
+  const unsigned t = threadIdx.x;
+  const int64_t i = blk + t;
   const bool valid = i < A.C;
+  auto at = [&](auto *base, int e) { return base + ((int64_t)e * A.C + blk); };  // wave-uniform
   const uint64_t gid = (uint64_t)(A.chain_offset + i);  // RNG is keyed by the GLOBAL chain id
   const bool resident = K.nchunks == 1;
 
@@ -356,7 +363,7 @@ __global__ void __launch_bounds__(kMaxBlock, kMinBlocks) mcmc_kernel(Consts K, M
   // adapts; the window (3 + 3 + 9 doubles of shifted sums) stays in its HBM arrays and is read-modified-written once per
   // proposal when the chain adapts at all — registers across the forward solve belong to the integrator.
   constexpr bool kWinRegs = D == 1;
-  double *lcs = lds + A.lc_off + threadIdx.x;  // D = 3: element e of this lane's factor at lcs[e * blockDim.x]
+  double *lcs = lds + A.lc_off + t;  // D = 3: element e of this lane's factor at lcs[e * blockDim.x]
   double V1 = 0.0;                             // D = 1: the proposal variance
   double wr[D], ws[D], wq[D * D];
   int32_t wn = 0;
@@ -369,34 +376,34 @@ __global__ void __launch_bounds__(kMaxBlock, kMinBlocks) mcmc_kernel(Consts K, M
   };
   if (valid) {
 #pragma unroll
-    for (int p = 0; p < D; ++p) q[p] = A.q[p * A.C + i];
-    ssq = A.ssq[i];
-    std2 = A.std2[i];
+    for (int p = 0; p < D; ++p) q[p] = at(A.q, p)[t];
+    ssq = at(A.ssq, 0)[t];
+    std2 = at(A.std2, 0)[t];
   }
   if constexpr (D == 1) {
-    if (valid) V1 = A.V[i];
+    if (valid) V1 = at(A.V, 0)[t];
   } else {
     double V[D * D], Lf[D * D];
 #pragma unroll
-    for (int e = 0; e < D * D; ++e) V[e] = valid ? A.V[e * A.C + i] : 0.0;
+    for (int e = 0; e < D * D; ++e) V[e] = valid ? at(A.V, e)[t] : 0.0;
     rsf::chol_lower<D>(V, Lf);
     store_factor(Lf);
   }
-  auto load_window = [&]() {
+  auto load_window = [&](unsigned t) {
 #pragma unroll
-    for (int p = 0; p < D; ++p) { wr[p] = A.wref[p * A.C + i]; ws[p] = A.wsum[p * A.C + i]; }
+    for (int p = 0; p < D; ++p) { wr[p] = at(A.wref, p)[t]; ws[p] = at(A.wsum, p)[t]; }
 #pragma unroll
-    for (int e = 0; e < D * D; ++e) wq[e] = A.wsq[e * A.C + i];
-    wn = A.wn[i];
+    for (int e = 0; e < D * D; ++e) wq[e] = at(A.wsq, e)[t];
+    wn = at(A.wn, 0)[t];
   };
-  auto store_window = [&]() {
+  auto store_window = [&](unsigned t) {
 #pragma unroll
-    for (int p = 0; p < D; ++p) { A.wref[p * A.C + i] = wr[p]; A.wsum[p * A.C + i] = ws[p]; }
+    for (int p = 0; p < D; ++p) { at(A.wref, p)[t] = wr[p]; at(A.wsum, p)[t] = ws[p]; }
 #pragma unroll
-    for (int e = 0; e < D * D; ++e) A.wsq[e * A.C + i] = wq[e];
-    A.wn[i] = wn;
+    for (int e = 0; e < D * D; ++e) at(A.wsq, e)[t] = wq[e];
+    at(A.wn, 0)[t] = wn;
   };
-  if (kWinRegs && A.adapt_mode != RSF_ADAPT_NONE && valid) load_window();
+  if (kWinRegs && A.adapt_mode != RSF_ADAPT_NONE && valid) load_window(t);
   uint32_t n_acc = 0, n_eval = 0, n_nonfinite = 0;
 
   float *lds32 = reinterpret_cast<float *>(lds);
@@ -408,13 +415,17 @@ __global__ void __launch_bounds__(kMaxBlock, kMinBlocks) mcmc_kernel(Consts K, M
 
   for (int64_t n = 0; n < A.n_iters; ++n) {
     const uint32_t it = (uint32_t)(A.iter_base + n);
-    const int64_t row = n * A.C + i;
+    const int64_t row0 = n * A.C + blk;  // trace row of this workgroup's first chain (wave-uniform)
+    // the lane's offset as this iteration sees it: opaque, so that the addresses built from it are formed where they are
+    // used instead of being hoisted out of the loop and kept (or spilled) across every forward solve
+    unsigned tl = t;
+    asm volatile("" : "+v"(tl));
     // ---- proposal, MCMC.py:497 ----
     double z[4] = {0.0, 0.0, 0.0, 0.0};
     if (REPLAY) {
       if (valid) {
 #pragma unroll
-        for (int p = 0; p < D; ++p) z[p] = A.z[row * D + p];
+        for (int p = 0; p < D; ++p) z[p] = (A.z + row0 * D)[tl * D + p];
       }
     } else {
       uint32_t w[4];
@@ -458,7 +469,7 @@ __global__ void __launch_bounds__(kMaxBlock, kMinBlocks) mcmc_kernel(Consts K, M
     if (inb) {
       double u;
       if (REPLAY) {
-        u = A.u[row];
+        u = (A.u + row0)[tl];
       } else {
         uint32_t w[4];
         rsf::draw_words(A.seed, gid, it, rsf::SLOT_U, w);
@@ -480,18 +491,18 @@ __global__ void __launch_bounds__(kMaxBlock, kMinBlocks) mcmc_kernel(Consts K, M
     // ---- sigma^2 Gibbs update with the post-accept SSq, MCMC.py:158-160 ----
     if (valid) {
       const double bval = 0.5 * (A.n0 * std2 + ssq);
-      const double g = REPLAY ? A.g[row] : rsf::gamma_draw(A.seed, gid, it, A.gd, A.gc);
+      const double g = REPLAY ? (A.g + row0)[tl] : rsf::gamma_draw(A.seed, gid, it, A.gd, A.gc);
       std2 = REPLAY ? bval / g : bval * rsf::fm::rcp(g);
       if (A.tq) {
 #pragma unroll
-        for (int p = 0; p < D; ++p) A.tq[row * D + p] = q[p];
+        for (int p = 0; p < D; ++p) (A.tq + row0 * D)[tl * D + p] = q[p];
       }
-      if (A.ts) A.ts[row] = std2;
-      if (A.ta) A.ta[row] = accept ? 1 : 0;
+      if (A.ts) (A.ts + row0)[tl] = std2;
+      if (A.ta) (A.ta + row0)[tl] = accept ? 1 : 0;
     }
     // ---- adaptation, MCMC.py:200-204, 523-527 ----
     if (A.adapt_mode != RSF_ADAPT_NONE && valid) {
-      if (!kWinRegs) load_window();
+      if (!kWinRegs) load_window(tl);
 #pragma unroll
       for (int p = 0; p < D; ++p) {
         ws[p] += q[p] - wr[p];
@@ -512,7 +523,7 @@ __global__ void __launch_bounds__(kMaxBlock, kMinBlocks) mcmc_kernel(Consts K, M
               V1 = Vn[0];
             } else {
 #pragma unroll
-              for (int e = 0; e < D * D; ++e) A.V[e * A.C + i] = Vn[e];
+              for (int e = 0; e < D * D; ++e) at(A.V, e)[tl] = Vn[e];
               store_factor(Ln);
             }
           }
@@ -523,17 +534,17 @@ __global__ void __launch_bounds__(kMaxBlock, kMinBlocks) mcmc_kernel(Consts K, M
 #pragma unroll
         for (int e = 0; e < D * D; ++e) wq[e] = 0.0;
       }
-      if (!kWinRegs) store_window();
+      if (!kWinRegs) store_window(tl);
     }
   }
 
   if (valid) {
 #pragma unroll
-    for (int p = 0; p < D; ++p) A.q[p * A.C + i] = q[p];
-    if constexpr (D == 1) A.V[i] = V1;
-    A.ssq[i] = ssq;
-    A.std2[i] = std2;
-    if (kWinRegs && A.adapt_mode != RSF_ADAPT_NONE) store_window();
+    for (int p = 0; p < D; ++p) at(A.q, p)[t] = q[p];
+    if constexpr (D == 1) at(A.V, 0)[t] = V1;
+    at(A.ssq, 0)[t] = ssq;
+    at(A.std2, 0)[t] = std2;
+    if (kWinRegs && A.adapt_mode != RSF_ADAPT_NONE) store_window(t);
   }
   // statistics: wave shuffle reduction, one atomic per wave and counter
   const unsigned long long s0 = rsf::wave_sum(n_acc), s1 = rsf::wave_sum(n_eval), s2 = rsf::wave_sum(n_nonfinite);

@@ -236,21 +236,25 @@ static double solve_dop853(const rsf_ctx *c, double dc, double a, double b, cons
  * squares of float residuals.  GPU and this restatement then differ only by the last-place behaviour of the hardware
  * v_exp_f32 / v_log_f32 / v_rcp_f32 against libm — which pins every constant and every term of the kernel far below
  * the 1e-3 band that separates float32 from float64 results. */
-typedef struct { float kia2, tc2, boa, kprime, k1k, via, bdc, hh, h, h6, hhd, hd, h6d, vref; } lane32;
+typedef struct { float kia2, tc2, boa, beta, c3, kvk, vref, cv, hh, h, h6, hhd, hd, h6d; } lane32;
 
-static void rhs32(const lane32 *L, int damp, float ms, float x, float vl, float *d0, float *d1, float *d2) {
-  float w = exp2f(fmaf(-L->boa, log2f(x), fmaf(ms, L->kia2, L->tc2)));   /* v/V_ref */
-  float rx = 1.0f / x;
-  float e1 = fmaf(-w, x, 1.0f);                                          /* RateStateModel.py:340 */
-  float e0 = fmaf(-L->vref, w, vl);                                      /* :343, in units of k' */
-  float bt = (L->bdc * e1) * rx;
-  float va = w * L->via;
-  float e2 = va * fmaf(L->kprime, e0, -bt);                              /* :346 */
+/* the RHS at (ms, x) in the product's regrouping (csrc/rsf_device_f32.h, rhs32): w = v/V_ref = 2^(kia2 ms + tc2 - (b/a) log2 x),
+ * d(ms)/dt = V_l - V_ref w, dtheta/dt = 1 - w x, and dV/dt = vk w g with g = (V_l - beta/x) + (beta - V_ref) w; the damping
+ * pass (RateStateModel.py:349-353) subtracts (kvk w) g from d(ms)/dt and from g.  Returns w g. */
+static float rhs32(const lane32 *L, int damp, float ms, float x, float vl, float *d0, float *d1) {
+  float lg = log2f(x), rx = 1.0f / x;
+  float w = exp2f(fmaf(-L->boa, lg, fmaf(ms, L->kia2, L->tc2)));
+  float t1 = fmaf(-L->beta, rx, vl);
+  float e0 = fmaf(-L->vref, w, vl);                                      /* RateStateModel.py:343, in units of k' */
+  float e1 = fmaf(-w, x, 1.0f);                                          /* :340 */
+  float g = fmaf(L->c3, w, t1);                                          /* :346, in units of vk w */
   if (damp) {                                                            /* :349-353 */
-    e0 = fmaf(-L->k1k, e2, e0);
-    e2 = va * fmaf(L->kprime, e0, -bt);
+    float kw = L->kvk * w;
+    e0 = fmaf(-kw, g, e0);
+    g = fmaf(-kw, g, g);
   }
-  *d0 = e0; *d1 = e1; *d2 = e2;
+  *d0 = e0; *d1 = e1;
+  return w * g;
 }
 
 static double solve_f32(const rsf_ctx *c, double dc, double a, double b, const double *data, double *acc, int64_t stride) {
@@ -260,10 +264,11 @@ static double solve_f32(const rsf_ctx *c, double dc, double a, double b, const d
   const double inv_a = 1.0 / a, inv_dc = 1.0 / dc, kprime = (1e-2 * 10) / dc, vdc = m->V_ref * inv_dc;
   lane32 L;
   L.kia2 = (float)(kprime * inv_a * log2e); L.tc2 = (float)(-m->mu_ref * inv_a * log2e); L.boa = (float)(b * inv_a);
-  L.kprime = (float)kprime; L.k1k = (float)(m->k1 / kprime); L.via = (float)(m->V_ref * inv_a); L.bdc = (float)(b * m->V_ref * inv_dc);
+  L.beta = (float)(b * m->V_ref * (1.0 / (1e-2 * 10))); L.c3 = (float)(b * m->V_ref * (1.0 / (1e-2 * 10)) - m->V_ref);
+  L.kvk = (float)(m->k1 * m->V_ref * inv_a); L.vref = (float)m->V_ref;
+  L.cv = (float)((h6 * (1.0 / c->delta_t)) * (m->V_ref * inv_a * kprime));
   L.hh = (float)hh; L.h = (float)h; L.h6 = (float)h6;
-  L.hhd = (float)(hh * vdc); L.hd = (float)(h * vdc); L.h6d = (float)(h6 * vdc); L.vref = (float)m->V_ref;
-  const float inv_dt = (float)(1.0 / c->delta_t);
+  L.hhd = (float)(hh * vdc); L.hd = (float)(h * vdc); L.h6d = (float)(h6 * vdc);
   float ms = (float)(m->mu_t_zero / kprime), x = 1.0f;
   double ssq = 0.0;
   int64_t j = 0;
@@ -277,16 +282,17 @@ static double solve_f32(const rsf_ctx *c, double dc, double a, double b, const d
       float vl0 = (float)(m->V_ref * (1 + exp(-t0 / 20) * sin(10 * t0)));
       float vlm = (float)(m->V_ref * (1 + exp(-tm / 20) * sin(10 * tm)));
       float vl1 = (float)(m->V_ref * (1 + exp(-t1 / 20) * sin(10 * t1)));
-      float a0, a1, a2, b0, b1, b2, c0, c1, c2, e0, e1, e2;
-      rhs32(&L, damp, ms, x, vl0, &a0, &a1, &a2);
-      rhs32(&L, damp, fmaf(L.hh, a0, ms), fmaf(L.hhd, a1, x), vlm, &b0, &b1, &b2);
-      rhs32(&L, damp, fmaf(L.hh, b0, ms), fmaf(L.hhd, b1, x), vlm, &c0, &c1, &c2);
-      rhs32(&L, damp, fmaf(L.h, c0, ms), fmaf(L.hd, c1, x), vl1, &e0, &e1, &e2);
-      ms = fmaf(L.h6, a0 + 2.0f * b0 + 2.0f * c0 + e0, ms);
-      x = fmaf(L.h6d, a1 + 2.0f * b1 + 2.0f * c1 + e1, x);
-      dv += L.h6 * (a2 + 2.0f * b2 + 2.0f * c2 + e2);
+      float a0, a1, b0, b1, c0, c1, e0, e1;
+      float wa = rhs32(&L, damp, ms, x, vl0, &a0, &a1);
+      float wb = rhs32(&L, damp, fmaf(L.hh, a0, ms), fmaf(L.hhd, a1, x), vlm, &b0, &b1);
+      float wc = rhs32(&L, damp, fmaf(L.hh, b0, ms), fmaf(L.hhd, b1, x), vlm, &c0, &c1);
+      float we = rhs32(&L, damp, fmaf(L.h, c0, ms), fmaf(L.hd, c1, x), vl1, &e0, &e1);
+      ms = fmaf(L.h6, fmaf(2.0f, b0 + c0, a0 + e0), ms);
+      x = fmaf(L.h6d, fmaf(2.0f, b1 + c1, a1 + e1), x);
+      float wsum = fmaf(2.0f, wb + wc, wa + we);
+      dv = S == 1 ? wsum : dv + wsum;
     }
-    float ak = dv * inv_dt;                                              /* RateStateModel.py:388, from the increment */
+    float ak = dv * L.cv;                                                /* RateStateModel.py:388, from the increment */
     if (acc) acc[k * stride] = (double)ak;
     if (data) { double r = (double)(ak - (float)data[k]); ssq = fma(r, r, ssq); }
   }
