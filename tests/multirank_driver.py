@@ -158,6 +158,13 @@ def main():
                 check(True, "")
             for e in engines:
                 e.comm_destroy()
+            # (c) the packaged form of (b): dist.run_single_process — shard, sample, init_all, grouped all-gather, destroy
+            pools, stats = rdist.run_single_process(engines, model, 1, data, q0, lo, hi, n_iters, 0, **{k: kw[k] for k in ("seed",)},
+                                                    mcmc_kwargs={k: v for k, v in kw.items() if k != "seed"}) if d == 1 else (None, None)
+            if pools is not None:
+                for r, pool in enumerate(pools):
+                    check(np.array_equal(to_np(pool), single), f"run_single_process world {world} rank {r}: pool != single-ctx run")
+                check(all(st["iters_done"] == n_iters for st in stats) and not any(e.world for e in engines), "run_single_process bookkeeping")
         for e in engines:
             e.close()
 

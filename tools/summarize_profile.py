@@ -45,7 +45,10 @@ def main():
                 per_dispatch[(r["Dispatch_Id"], r["Counter_Name"])] += float(r["Counter_Value"])
         for (_, name), v in per_dispatch.items():
             counters[name].append(v)
-    pmc = {k: sum(v) / len(v) for k, v in counters.items()}
+    # per-launch figure = the MEDIAN over the launches of the pass (one launch of a pass occasionally carries another
+    # kernel's write-back: e.g. WRITE_SIZE 131328 / 131328 / 296535 KiB for three identical DOP853 launches)
+    pmc = {k: sorted(v)[len(v) // 2] if len(v) % 2 else 0.5 * (sorted(v)[len(v) // 2 - 1] + sorted(v)[len(v) // 2]) for k, v in counters.items()}
+    summary["pmc_launches_per_counter"] = {k: len(v) for k, v in counters.items()}
     summary["pmc_per_launch"] = pmc
     if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
         # rocprofv3 reports KiB; on gfx950 FETCH_SIZE counts 64 B per 128-B read request for wide coalesced
