@@ -4,8 +4,8 @@ A/B timing of kernel builds in ONE process with interleaved rounds (same device,
 
   python tools/ab_bench.py [--chains C] [--nsteps N] [--iters I] [--rounds R] name=path.so ...
 
-Each variant is a build of csrc/rsf_hip.hip (e.g. with -DRSF_NO_INCREMENTAL); "default" is the
-in-tree librsf_hip.so.  Prints median / min milliseconds per launch and ODE-steps*chains/s.
+Each variant is a build of an edited copy of csrc/ (the kernels' tunables are constexpr values in rsf_device.h /
+rsf_kernels.h: copy the directory, change one, `make`, pass the .so here); "default" is the in-tree librsf_hip.so.  Prints median / min milliseconds per launch and ODE-steps*chains/s.
 """
 import argparse
 import ctypes
