@@ -89,12 +89,12 @@ class RSF:
         return _figures.trace_with_density(qparams[0, :], f"$d_c={dc:.2f}\\,\\mu m$ with {self.format} formatting", kde)
 
     def perform_sampling_and_plotting(self, data, dc, nsamples, model_lstm):
-        index = np.where(self.dc_list == dc)[0][0] if dc in self.dc_list else -1
-        if index == -1:
+        hits = np.flatnonzero(np.asarray(self.dc_list) == dc)  # the series of true value dc_list[i] is data[i*N:(i+1)*N], RSF.py:874-882
+        if hits.size == 0:
             print(f"Error: dc value {dc} not found in dc_list.")
             return
-        start = index * self.model.num_tsteps
-        noisy_data = data[start:start + self.model.num_tsteps]
+        n = self.model.num_tsteps
+        noisy_data = data[int(hits[0]) * n:(int(hits[0]) + 1) * n]
         print(f"--- Dc is {dc} ---")
         mc = MCMC(self.model, noisy_data, dc, self.qpriors, self.qstart, lstm_model=model_lstm, nsamples=nsamples,
                   verbose=self.verbose)

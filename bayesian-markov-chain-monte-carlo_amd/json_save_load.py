@@ -11,7 +11,7 @@ import numpy as np
 def numpy_array_encoder(obj):
     if isinstance(obj, np.ndarray):
         return {"__ndarray__": True, "data": obj.tolist(), "shape": obj.shape}
-    raise TypeError(f"Object of type '{type(obj).__name__}' is not JSON serializable")
+    raise TypeError(f"json_save_load: cannot encode a {type(obj).__name__} (only ndarrays get a wire form; the rest must be plain JSON)")
 
 
 def numpy_array_decoder(dct):
