@@ -64,6 +64,7 @@ __device__ __forceinline__ Lane32 make_lane32(double dc, double a, double b, con
 // → d = (d(ms)/dt, dtheta/dt) and w g, the stage's dV/dt in units of vk.
 template <bool DAMP>
 __device__ __forceinline__ float rhs32(float2v s, float vl, const Lane32 &L, float2v &d) {
+#pragma clang fp contract(off)  // every fused multiply-add of this path is written out: one-chain and two-chain forms round alike
   const float lg = __builtin_amdgcn_logf(s.y), rx = __builtin_amdgcn_rcpf(s.y);
   const float w = __builtin_amdgcn_exp2f(__builtin_fmaf(-L.boa, lg, __builtin_fmaf(s.x, L.kia2, L.tc2)));
   const float t1 = __builtin_fmaf(-L.beta, rx, vl);
@@ -81,6 +82,7 @@ __device__ __forceinline__ float rhs32(float2v s, float vl, const Lane32 &L, flo
 // one RK4 step; returns the weighted sum k1 + 2 k2 + 2 k3 + k4 of dV/dt in units of vk
 template <bool DAMP>
 __device__ __forceinline__ float rk4_step32(float2v &s, float vl0, float vlm, float vl1, const Lane32 &L) {
+#pragma clang fp contract(off)  // every fused multiply-add of this path is written out: one-chain and two-chain forms round alike
   float2v a, b, c, e;
   const float wa = rhs32<DAMP>(s, vl0, L, a);
   const float wb = rhs32<DAMP>(pk_fma(L.chh, a, s), vlm, L, b);
@@ -113,6 +115,7 @@ __device__ __forceinline__ void stage_chunk32(float *lds, const Consts &K, int k
 template <bool DAMP, bool WANT_SSQ, bool WANT_ACC, bool S1>
 __device__ __forceinline__ void integrate_chunk32(const float *lds, const Consts &K, const Lane32 &L, int k0, int kn,
                                                   float2v &st, double &ssq, double *acc_out, int64_t stride) {
+#pragma clang fp contract(off)  // every fused multiply-add of this path is written out: one-chain and two-chain forms round alike
   const float *ld = lds + lds_data_offset32(K);
   auto emit = [&](int kk, float dv, float obs) {
     const float ak = dv * L.cv;  // RateStateModel.py:388, from the interval's velocity increment
@@ -164,6 +167,111 @@ __device__ __forceinline__ double solve32(float *lds, const Consts &K, bool resi
     }
   }
   return ssq;
+}
+
+// ---------------------------------------------------------------------------------------------
+// TWO chains per lane (the float32 sampler kernel): every quantity of the solve is a packed pair {chain A, chain B}, so
+// each arithmetic instruction is a v_pk_*_f32 that advances both chains — 2x the work per issue slot, which is what
+// float32 can give on this part (plain v_fma_f32 runs at the float64 rate).  Operation for operation the same
+// arithmetic as the one-chain functions above (v_pk_fma_f32 is an IEEE fma per half), so a chain's result does not
+// depend on which form integrated it (tested: the sampler against the forward kernel and the float32 restatement).
+// The three transcendentals per stage are issued once per chain.
+// ---------------------------------------------------------------------------------------------
+struct Lane32x2 {
+  float2v kia2, tc2, boa, beta, c3, kvk, cv, hhd, hd, h6d;  // per chain (see Lane32)
+  float2v vref, hh, h, h6;                                   // the same value in both halves
+};
+
+__device__ __forceinline__ Lane32x2 make_lane32x2(const double dc[2], const double a[2], const double b[2], const Consts &K) {
+  const Lane32 A = make_lane32(dc[0], a[0], b[0], K), B = make_lane32(dc[1], a[1], b[1], K);
+  Lane32x2 L;
+  L.kia2 = float2v{A.kia2, B.kia2}; L.tc2 = float2v{A.tc2, B.tc2}; L.boa = float2v{A.boa, B.boa};
+  L.beta = float2v{A.beta, B.beta}; L.c3 = float2v{A.c3, B.c3}; L.kvk = float2v{A.kvk, B.kvk}; L.cv = float2v{A.cv, B.cv};
+  L.hhd = float2v{A.chh.y, B.chh.y}; L.hd = float2v{A.ch.y, B.ch.y}; L.h6d = float2v{A.ch6.y, B.ch6.y};
+  L.vref = float2v{A.vref, A.vref}; L.hh = float2v{A.chh.x, A.chh.x}; L.h = float2v{A.ch.x, A.ch.x}; L.h6 = float2v{A.ch6.x, A.ch6.x};
+  return L;
+}
+
+template <bool DAMP>
+__device__ __forceinline__ float2v rhs32x2(float2v ms, float2v x, float vl, const Lane32x2 &L, float2v &d0, float2v &d1) {
+#pragma clang fp contract(off)  // every fused multiply-add of this path is written out: one-chain and two-chain forms round alike
+  const float2v lg = {__builtin_amdgcn_logf(x.x), __builtin_amdgcn_logf(x.y)};
+  const float2v rx = {__builtin_amdgcn_rcpf(x.x), __builtin_amdgcn_rcpf(x.y)};
+  const float2v arg = pk_fma(-L.boa, lg, pk_fma(ms, L.kia2, L.tc2));
+  const float2v w = {__builtin_amdgcn_exp2f(arg.x), __builtin_amdgcn_exp2f(arg.y)};
+  const float2v vl2 = {vl, vl}, one = {1.0f, 1.0f};
+  const float2v t1 = pk_fma(-L.beta, rx, vl2);
+  d0 = pk_fma(-L.vref, w, vl2);
+  d1 = pk_fma(-w, x, one);
+  float2v g = pk_fma(L.c3, w, t1);
+  if (DAMP) {
+    const float2v kw = L.kvk * w;
+    d0 = pk_fma(-kw, g, d0);
+    g = pk_fma(-kw, g, g);
+  }
+  return w * g;
+}
+
+template <bool DAMP>
+__device__ __forceinline__ float2v rk4_step32x2(float2v &ms, float2v &x, float vl0, float vlm, float vl1, const Lane32x2 &L) {
+#pragma clang fp contract(off)  // every fused multiply-add of this path is written out: one-chain and two-chain forms round alike
+  float2v a0, a1, b0, b1, c0, c1, e0, e1;
+  const float2v wa = rhs32x2<DAMP>(ms, x, vl0, L, a0, a1);
+  const float2v wb = rhs32x2<DAMP>(pk_fma(L.hh, a0, ms), pk_fma(L.hhd, a1, x), vlm, L, b0, b1);
+  const float2v wc = rhs32x2<DAMP>(pk_fma(L.hh, b0, ms), pk_fma(L.hhd, b1, x), vlm, L, c0, c1);
+  const float2v we = rhs32x2<DAMP>(pk_fma(L.h, c0, ms), pk_fma(L.hd, c1, x), vl1, L, e0, e1);
+  const float2v two = {2.0f, 2.0f};
+  ms = pk_fma(L.h6, pk_fma(two, b0 + c0, a0 + e0), ms);
+  x = pk_fma(L.h6d, pk_fma(two, b1 + c1, a1 + e1), x);
+  return pk_fma(two, wb + wc, wa + we);
+}
+
+// sums of squares of two chains that share the observation series (both belong to the workgroup's group)
+template <bool DAMP>
+__device__ __forceinline__ void solve32x2(float *lds, const Consts &K, bool resident, const bool active[2], const double dc[2],
+                                          const double a[2], const double b[2], double ssq[2]) {
+#pragma clang fp contract(off)  // every fused multiply-add of this path is written out: one-chain and two-chain forms round alike
+  const Lane32x2 L = make_lane32x2(dc, a, b, K);
+  float2v ms = {(float)(K.mu0 / ((1e-2 * 10) / dc[0])), (float)(K.mu0 / ((1e-2 * 10) / dc[1]))}, x = {1.0f, 1.0f};
+  const bool any = active[0] || active[1];
+  ssq[0] = ssq[1] = 0.0;
+  if (any) {
+    const double d0 = (double)(float)K.data[0];
+    ssq[0] = ssq[1] = d0 * d0;
+  }
+  auto emit = [&](float2v dv, float obs) {
+    const float2v ak = dv * L.cv;  // RateStateModel.py:388, from the interval's velocity increment
+    const double r0 = (double)(ak.x - obs), r1 = (double)(ak.y - obs);
+    ssq[0] = __builtin_fma(r0, r0, ssq[0]);
+    ssq[1] = __builtin_fma(r1, r1, ssq[1]);
+  };
+  for (int k0 = 1; k0 < K.nout; k0 += K.kc) {
+    const int kn = min(K.kc, K.nout - k0);
+    if (!resident) stage_chunk32(lds, K, k0, kn);
+    if (!any) continue;
+    const float *ld = lds + lds_data_offset32(K);
+    int kk = 0;
+    if (K.S == 1) {
+      constexpr int NU = 8;
+      for (; kk + NU <= kn; kk += NU) {
+        const float *v = lds + 2 * kk;
+        float obs[NU];
+        float2v dv[NU];
+#pragma unroll
+        for (int j = 0; j < NU; ++j) obs[j] = ld[kk + j];
+#pragma unroll
+        for (int j = 0; j < NU; ++j) dv[j] = rk4_step32x2<DAMP>(ms, x, v[2 * j], v[2 * j + 1], v[2 * j + 2], L);
+#pragma unroll
+        for (int j = 0; j < NU; ++j) emit(dv[j], obs[j]);
+      }
+    }
+    int j = 2 * K.S * kk;
+    for (; kk < kn; ++kk) {
+      float2v dv = {0.0f, 0.0f};
+      for (int sub = 0; sub < K.S; ++sub, j += 2) dv += rk4_step32x2<DAMP>(ms, x, lds[j], lds[j + 1], lds[j + 2], L);
+      emit(dv, ld[kk]);
+    }
+  }
 }
 
 }  // namespace f32

@@ -175,10 +175,23 @@ Consts make_consts(const rsf_ctx *c, const double *data) {
 
 unsigned grid_for(const rsf_ctx *c, int64_t n) { return (unsigned)((n + c->block - 1) / c->block); }
 
+int mode_of(const rsf_ctx *c) {
+  return (c->m.flags & RSF_FLAG_DOP853) ? DOP853 : ((c->m.flags & RSF_FLAG_FP32_SOLVE) ? RK4_F32 : RK4_F64);
+}
+
+// chains a lane of the sampler kernel carries: two in the float32 mode (mcmc_f32x2_kernel), else one
+int chains_per_lane(const rsf_ctx *c) { return mode_of(c) == RK4_F32 ? 2 : 1; }
+
 // LDS of a sampler launch: the table chunk, and behind it the per-lane Cholesky factors of a three-parameter chain
 // (six doubles per lane, mcmc_kernel)
 size_t mcmc_lds_bytes(const rsf_ctx *c) {
-  return c->lds_bytes + (c->mc.n_params == 3 ? (size_t)6 * sizeof(double) * (size_t)c->block : 0);
+  return c->lds_bytes + (c->mc.n_params == 3 ? (size_t)6 * sizeof(double) * (size_t)c->block * (size_t)chains_per_lane(c) : 0);
+}
+
+// workgroups of a sampler launch over n chains
+unsigned mcmc_grid(const rsf_ctx *c, int64_t n) {
+  const int64_t per = (int64_t)c->block * chains_per_lane(c);
+  return (unsigned)((n + per - 1) / per);
 }
 
 // [n][d] (the C ABI's layout) <-> [d][n] (the kernels' structure of arrays); both device pointers, on the ctx stream
@@ -191,17 +204,20 @@ int transpose(rsf_ctx *c, int64_t n, int d, const double *src, double *dst, bool
   return RSF_OK;
 }
 
-int mode_of(const rsf_ctx *c) {
-  return (c->m.flags & RSF_FLAG_DOP853) ? DOP853 : ((c->m.flags & RSF_FLAG_FP32_SOLVE) ? RK4_F32 : RK4_F64);
-}
-
 template <int D, bool DAMP, int MODE>
 int launch_mcmc(rsf_ctx *c, const Consts &K, const McmcArgs &A, bool replay) {
-  const dim3 grid(grid_for(c, A.C)), block(c->block);
-  if (replay)
-    hipLaunchKernelGGL((mcmc_kernel<D, DAMP, true, MODE>), grid, block, mcmc_lds_bytes(c), c->stream, K, A);
-  else
-    hipLaunchKernelGGL((mcmc_kernel<D, DAMP, false, MODE>), grid, block, mcmc_lds_bytes(c), c->stream, K, A);
+  const dim3 grid(mcmc_grid(c, A.C)), block(c->block);
+  if constexpr (MODE == RK4_F32) {
+    if (replay)
+      hipLaunchKernelGGL((mcmc_f32x2_kernel<D, DAMP, true>), grid, block, mcmc_lds_bytes(c), c->stream, K, A);
+    else
+      hipLaunchKernelGGL((mcmc_f32x2_kernel<D, DAMP, false>), grid, block, mcmc_lds_bytes(c), c->stream, K, A);
+  } else {
+    if (replay)
+      hipLaunchKernelGGL((mcmc_kernel<D, DAMP, true, MODE>), grid, block, mcmc_lds_bytes(c), c->stream, K, A);
+    else
+      hipLaunchKernelGGL((mcmc_kernel<D, DAMP, false, MODE>), grid, block, mcmc_lds_bytes(c), c->stream, K, A);
+  }
   return RSF_OK;
 }
 
@@ -280,7 +296,7 @@ constexpr int64_t kReplayGraphMaxChains = 4096;  // beyond this the copies domin
 template <int D, bool DAMP>
 const void *replay_kernel_m(const rsf_ctx *c) {
   switch (mode_of(c)) {
-    case RK4_F32: return (const void *)mcmc_kernel<D, DAMP, true, RK4_F32>;
+    case RK4_F32: return (const void *)mcmc_f32x2_kernel<D, DAMP, true>;
     case DOP853: return (const void *)mcmc_kernel<D, DAMP, true, DOP853>;
     default: return (const void *)mcmc_kernel<D, DAMP, true, RK4_F64>;
   }
@@ -329,7 +345,7 @@ int run_replay_graph(rsf_ctx *c, const Consts &K, McmcArgs A, const double *z, c
   void *params[2] = {&Kc, &A};
   hipKernelNodeParams kp{};
   kp.func = const_cast<void *>(fn);
-  kp.gridDim = dim3(grid_for(c, A.C)); kp.blockDim = dim3(c->block);
+  kp.gridDim = dim3(mcmc_grid(c, A.C)); kp.blockDim = dim3(c->block);
   kp.sharedMemBytes = (unsigned)mcmc_lds_bytes(c);
   kp.kernelParams = params;
   kp.extra = nullptr;
@@ -672,8 +688,11 @@ int rsf_mcmc_init(rsf_ctx *c, const rsf_mcmc_config *cfg, const double *q0, cons
   if (cfg->adapt_mode < 0 || cfg->adapt_mode > RSF_ADAPT_AM || (cfg->adapt_mode && cfg->adapt_interval < 2))
     return fail(RSF_ERR_INVALID, "rsf_mcmc_init: bad adapt_mode / adapt_interval");
   const int G = cfg->n_groups > 1 ? cfg->n_groups : 1;
-  if (cfg->n_groups < 0 || cfg->n_chains % G || (G > 1 && (cfg->n_chains / G) % c->block))
-    return fail(RSF_ERR_INVALID, "rsf_mcmc_init: n_chains/n_groups must be a whole multiple of the workgroup size (%d)", c->block);
+  // a workgroup's chains share one observation series: a group must be whole workgroups' worth of chains
+  const int wg_chains = c->block * chains_per_lane(c);
+  if (cfg->n_groups < 0 || cfg->n_chains % G || (G > 1 && (cfg->n_chains / G) % wg_chains))
+    return fail(RSF_ERR_INVALID, "rsf_mcmc_init: n_chains/n_groups must be a whole multiple of a workgroup's chains (%d%s)", wg_chains,
+                chains_per_lane(c) == 2 ? ": the float32 sampler carries two chains per lane" : "");
   DeviceGuard guard(c->device);
   if (!guard.ok) return fail(RSF_ERR_DEVICE, "rsf_mcmc_init: cannot select device %d", c->device);
   const int d = cfg->n_params;

@@ -339,6 +339,7 @@ struct McmcArgs {
 
 template <int D, bool DAMP, bool REPLAY, int MODE>
 __global__ void __launch_bounds__(kMaxBlock, kMinBlocks) mcmc_kernel(Consts K, McmcArgs A) {
+  static_assert(MODE == RK4_F64 || MODE == DOP853, "the float32 sampler is mcmc_f32x2_kernel (two chains per lane)");
   extern __shared__ __attribute__((aligned(16))) double lds[];
   rsf::select_group(K);
   // Per-chain arrays are addressed as (wave-uniform row pointer)[threadIdx.x]: the row pointer — array + element * C + the
@@ -406,10 +407,8 @@ __global__ void __launch_bounds__(kMaxBlock, kMinBlocks) mcmc_kernel(Consts K, M
   if (kWinRegs && A.adapt_mode != RSF_ADAPT_NONE && valid) load_window(t);
   uint32_t n_acc = 0, n_eval = 0, n_nonfinite = 0;
 
-  float *lds32 = reinterpret_cast<float *>(lds);
   if (resident) {
-    if constexpr (MODE == RK4_F32) rsf::f32::stage_chunk32(lds32, K, 1, K.nout - 1);
-    else if constexpr (MODE == DOP853) rsf::dp::stage_chunk_dp(lds, K, 1, K.nout - 1);
+    if constexpr (MODE == DOP853) rsf::dp::stage_chunk_dp(lds, K, 1, K.nout - 1);
     else rsf::stage_chunk(lds, K, 1, K.nout - 1);
   }
 
@@ -460,8 +459,7 @@ __global__ void __launch_bounds__(kMaxBlock, kMinBlocks) mcmc_kernel(Consts K, M
     double ssqn = 0.0;
     // (a wave with no in-bounds lane skips the solve when the tables are resident: no barrier inside)
     if (!resident || __any(inb)) {
-      if constexpr (MODE == RK4_F32) ssqn = rsf::f32::solve32<DAMP, true, false>(lds32, K, resident, inb, qn[0], an, bn, nullptr, 0);
-      else if constexpr (MODE == DOP853) ssqn = rsf::dp::solve<DAMP, true, false>(lds, K, resident, inb, qn[0], an, bn, nullptr, 0);
+      if constexpr (MODE == DOP853) ssqn = rsf::dp::solve<DAMP, true, false>(lds, K, resident, inb, qn[0], an, bn, nullptr, 0);
       else ssqn = rsf::solve<DAMP, true, false, (D == 1 ? 2 : kD3Trip) * rsf::kTightUnroll>(lds, K, resident, inb, qn[0], an, bn, nullptr, 0);
     }
     // ---- accept / reject, MCMC.py:327-333 ----
@@ -545,6 +543,253 @@ __global__ void __launch_bounds__(kMaxBlock, kMinBlocks) mcmc_kernel(Consts K, M
     at(A.ssq, 0)[t] = ssq;
     at(A.std2, 0)[t] = std2;
     if (kWinRegs && A.adapt_mode != RSF_ADAPT_NONE) store_window(t);
+  }
+  // statistics: wave shuffle reduction, one atomic per wave and counter
+  const unsigned long long s0 = rsf::wave_sum(n_acc), s1 = rsf::wave_sum(n_eval), s2 = rsf::wave_sum(n_nonfinite);
+  if ((threadIdx.x & 63) == 0) {
+    if (s0) atomicAdd(&A.stats[0], s0);
+    if (s1) atomicAdd(&A.stats[1], s1);
+    if (s2) atomicAdd(&A.stats[2], s2);
+  }
+}
+
+// The float32 sampler (RSF_FLAG_FP32_SOLVE): the same iteration as mcmc_kernel, with TWO chains per lane, because its
+// solve advances two chains per packed instruction (rsf_device_f32.h, solve32x2).  Chain slot s of lane t of workgroup w
+// is chain w * 2 * blockDim + s * blockDim + t, so that both slots read and write coalesced runs.  (A second kernel
+// rather than a chains-per-lane parameter of mcmc_kernel: written that way, the float64 kernels — which sit at 252-256
+// registers — came out with 12-44 B of scratch per lane.)  The sampler logic itself stays float64.
+// Per-chain sampler state of one slot:
+template <int D>
+struct Chain {
+  double q[D], ssq, std2;
+  double V1;                   // D = 1: the proposal variance
+  double wr[D], ws[D], wq[D * D];  // adaptation window (D = 1 only: held in registers for the launch)
+  int32_t wn;
+  bool valid;
+  uint64_t gid;                // RNG is keyed by the GLOBAL chain id
+};
+
+template <int D, bool DAMP, bool REPLAY>
+__global__ void __launch_bounds__(kMaxBlock, kMinBlocks) mcmc_f32x2_kernel(Consts K, McmcArgs A) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  constexpr int NC = 2;  // chains per lane
+  // Per-chain arrays are addressed as (wave-uniform row pointer)[threadIdx.x]: the row pointer — array + element * C + the
+  // slot's first chain — is scalar arithmetic, and the lane's share is one small 32-bit offset, so no access keeps a
+  // 64-bit per-lane address alive across the forward solve (with plain [e * C + i] indexing the compiler hoisted two dozen
+  // of them out of the iteration loop: 224 B of scratch per lane in the three-parameter kernel).
+  const int64_t blk = (int64_t)blockIdx.x * blockDim.x * NC;  // first chain of this workgroup
+  if (K.group_chains > 0) K.data += (blk / K.group_chains) * K.nout;  // the observation series of the workgroup's chain group
+  const unsigned t = threadIdx.x;
+  auto at = [&](auto *base, int e, int s) { return base + ((int64_t)e * A.C + blk + (int64_t)s * blockDim.x); };  // wave-uniform
+  const bool resident = K.nchunks == 1;
+
+  // What a proposal needs of the covariance V is its lower Cholesky factor (MCMC.py:497).  D = 1: one double, sqrt(V), kept
+  // in a register with the three doubles of the adaptation window.  D = 3: the factor's six doubles live in LDS, one slot
+  // per chain behind the table chunk (lc[e][slot][lane]: conflict-free), formed from V once per launch and again when the
+  // chain adapts; the window (3 + 3 + 9 doubles of shifted sums) stays in its HBM arrays and is read-modified-written once
+  // per proposal when the chain adapts at all — registers across the forward solve belong to the integrator.
+  constexpr bool kWinRegs = D == 1;
+  double *lcs = lds + A.lc_off + t;  // D = 3: element e of slot s's factor at lcs[(e * NC + s) * blockDim.x]
+  Chain<D> ch[NC];
+  auto store_factor = [&](int s, const double *Lf) {  // row-major lower triangle
+    int e = 0;
+#pragma unroll
+    for (int p = 0; p < D; ++p)
+#pragma unroll
+      for (int r = 0; r <= p; ++r) lcs[((e++) * NC + s) * blockDim.x] = Lf[p * D + r];
+  };
+  auto load_window = [&](int s, unsigned t) {
+    Chain<D> &c = ch[s];
+#pragma unroll
+    for (int p = 0; p < D; ++p) { c.wr[p] = at(A.wref, p, s)[t]; c.ws[p] = at(A.wsum, p, s)[t]; }
+#pragma unroll
+    for (int e = 0; e < D * D; ++e) c.wq[e] = at(A.wsq, e, s)[t];
+    c.wn = at(A.wn, 0, s)[t];
+  };
+  auto store_window = [&](int s, unsigned t) {
+    const Chain<D> &c = ch[s];
+#pragma unroll
+    for (int p = 0; p < D; ++p) { at(A.wref, p, s)[t] = c.wr[p]; at(A.wsum, p, s)[t] = c.ws[p]; }
+#pragma unroll
+    for (int e = 0; e < D * D; ++e) at(A.wsq, e, s)[t] = c.wq[e];
+    at(A.wn, 0, s)[t] = c.wn;
+  };
+#pragma unroll
+  for (int s = 0; s < NC; ++s) {
+    Chain<D> &c = ch[s];
+    const int64_t i = blk + (int64_t)s * blockDim.x + t;
+    c.valid = i < A.C;
+    c.gid = (uint64_t)(A.chain_offset + i);
+    c.ssq = 0.0; c.std2 = 1.0; c.V1 = 0.0; c.wn = 0;
+#pragma unroll
+    for (int p = 0; p < D; ++p) c.q[p] = 1.0;
+    if (c.valid) {
+#pragma unroll
+      for (int p = 0; p < D; ++p) c.q[p] = at(A.q, p, s)[t];
+      c.ssq = at(A.ssq, 0, s)[t];
+      c.std2 = at(A.std2, 0, s)[t];
+    }
+    if constexpr (D == 1) {
+      if (c.valid) c.V1 = at(A.V, 0, s)[t];
+    } else {
+      double V[D * D], Lf[D * D];
+#pragma unroll
+      for (int e = 0; e < D * D; ++e) V[e] = c.valid ? at(A.V, e, s)[t] : 0.0;
+      rsf::chol_lower<D>(V, Lf);
+      store_factor(s, Lf);
+    }
+    if (kWinRegs && A.adapt_mode != RSF_ADAPT_NONE && c.valid) load_window(s, t);
+  }
+  uint32_t n_acc = 0, n_eval = 0, n_nonfinite = 0;
+
+  float *lds32 = reinterpret_cast<float *>(lds);
+  if (resident) rsf::f32::stage_chunk32(lds32, K, 1, K.nout - 1);
+
+  for (int64_t n = 0; n < A.n_iters; ++n) {
+    const uint32_t it = (uint32_t)(A.iter_base + n);
+    // the lane's offset as this iteration sees it: opaque, so that the addresses built from it are formed where they are
+    // used instead of being hoisted out of the loop and kept (or spilled) across every forward solve
+    unsigned tl = t;
+    asm volatile("" : "+v"(tl));
+    double qn[NC][D], ssqn[NC];
+    bool inb[NC];
+    // ---- proposal, MCMC.py:497 ----
+#pragma unroll
+    for (int s = 0; s < NC; ++s) {
+      const Chain<D> &c = ch[s];
+      const int64_t row0 = n * A.C + blk + (int64_t)s * blockDim.x;  // trace row of the slot's first chain (wave-uniform)
+      double z[4] = {0.0, 0.0, 0.0, 0.0};
+      if (REPLAY) {
+        if (c.valid) {
+#pragma unroll
+          for (int p = 0; p < D; ++p) z[p] = (A.z + row0 * D)[tl * D + p];
+        }
+      } else {
+        uint32_t w[4];
+        rsf::draw_words(A.seed, c.gid, it, rsf::SLOT_Z01, w);
+        rsf::normal_pair(w, z[0], z[1]);
+        if (D > 2) {
+          rsf::draw_words(A.seed, c.gid, it, rsf::SLOT_Z2, w);
+          rsf::normal_pair(w, z[2], z[3]);
+        }
+      }
+      if constexpr (D == 1) {
+        double Lc;
+        rsf::chol_lower<1>(&c.V1, &Lc);  // sqrt(V), or 0 where V is not positive
+        qn[s][0] = c.q[0] + Lc * z[0];
+      } else {
+        int e = 0;
+#pragma unroll
+        for (int p = 0; p < D; ++p) {
+          double acc = c.q[p];
+#pragma unroll
+          for (int r = 0; r <= p; ++r) acc += lcs[((e++) * NC + s) * blockDim.x] * z[r];
+          qn[s][p] = acc;
+        }
+      }
+      inb[s] = c.valid;
+#pragma unroll
+      for (int p = 0; p < D; ++p) inb[s] = inb[s] && (qn[s][p] > A.lo[p]) && (qn[s][p] < A.hi[p]);  // strict box, MCMC.py:318-320
+      ssqn[s] = 0.0;
+    }
+    // ---- likelihood: forward solve only for in-bounds proposals, MCMC.py:322-324 ----
+    // (a wave with no in-bounds lane skips the solve when the tables are resident: no barrier inside)
+    if (!resident || __any(inb[0] || inb[1])) {
+      double dcn[2], an[2], bn[2];
+#pragma unroll
+      for (int s = 0; s < 2; ++s) { dcn[s] = qn[s][0]; an[s] = D == 3 ? qn[s][D - 2] : K.a_def; bn[s] = D == 3 ? qn[s][D - 1] : K.b_def; }
+      rsf::f32::solve32x2<DAMP>(lds32, K, resident, inb, dcn, an, bn, ssqn);
+    }
+#pragma unroll
+    for (int s = 0; s < NC; ++s) {
+      Chain<D> &c = ch[s];
+      const int64_t row0 = n * A.C + blk + (int64_t)s * blockDim.x;
+      // ---- accept / reject, MCMC.py:327-333 ----
+      bool accept = false;
+      if (inb[s]) {
+        double u;
+        if (REPLAY) {
+          u = (A.u + row0)[tl];
+        } else {
+          uint32_t w[4];
+          rsf::draw_words(A.seed, c.gid, it, rsf::SLOT_U, w);
+          u = rsf::u53(w[0], w[1]);
+        }
+        // (replaying recorded variates follows the reference's arithmetic to the last bit: IEEE division, libm-grade log;
+        //  the sampler proper uses the kernel's own reciprocal and log — the same value to ~1 ulp)
+        const double logalpha = fmin(REPLAY ? 0.5 * (c.ssq - ssqn[s]) / c.std2 : (0.5 * (c.ssq - ssqn[s])) * rsf::fm::rcp(c.std2), 0.0);
+        accept = logalpha > (REPLAY ? log(u) : rsf::rng_log(u));  // NaN compares false => reject
+        ++n_eval;
+        if (!isfinite(ssqn[s])) ++n_nonfinite;
+        if (accept) {
+          c.ssq = ssqn[s];
+#pragma unroll
+          for (int p = 0; p < D; ++p) c.q[p] = qn[s][p];
+          ++n_acc;
+        }
+      }
+      // ---- sigma^2 Gibbs update with the post-accept SSq, MCMC.py:158-160 ----
+      if (c.valid) {
+        const double bval = 0.5 * (A.n0 * c.std2 + c.ssq);
+        const double g = REPLAY ? (A.g + row0)[tl] : rsf::gamma_draw(A.seed, c.gid, it, A.gd, A.gc);
+        c.std2 = REPLAY ? bval / g : bval * rsf::fm::rcp(g);
+        if (A.tq) {
+#pragma unroll
+          for (int p = 0; p < D; ++p) (A.tq + row0 * D)[tl * D + p] = c.q[p];
+        }
+        if (A.ts) (A.ts + row0)[tl] = c.std2;
+        if (A.ta) (A.ta + row0)[tl] = accept ? 1 : 0;
+      }
+      // ---- adaptation, MCMC.py:200-204, 523-527 ----
+      if (A.adapt_mode != RSF_ADAPT_NONE && c.valid) {
+        if (!kWinRegs) load_window(s, tl);
+#pragma unroll
+        for (int p = 0; p < D; ++p) {
+          c.ws[p] += c.q[p] - c.wr[p];
+#pragma unroll
+          for (int r = 0; r < D; ++r) c.wq[p * D + r] += (c.q[p] - c.wr[p]) * (c.q[r] - c.wr[r]);
+        }
+        ++c.wn;
+        if ((A.iter_base + n + 1) % A.adapt_interval == 0) {
+          if (c.wn >= 2) {
+            const double nn = (double)c.wn;
+            double Vn[D * D], Ln[D * D];
+            if (A.adapt_mode == RSF_ADAPT_REFERENCE_DICT) {
+              // d := len(qpriors.keys()) (2 for {1: lo, 2: hi}), and the Cholesky FACTOR becomes the next covariance
+              // (one-parameter chains only: rsf_mcmc_init refuses the mode for D = 3)
+              if (rsf::window_covariance<1>(c.ws, c.wq, nn, A.dict_scale, Vn, Ln)) c.V1 = Ln[0];
+            } else if (rsf::window_covariance<D>(c.ws, c.wq, nn, 2.38 * 2.38 / (double)D, Vn, Ln)) {
+              if constexpr (D == 1) {
+                c.V1 = Vn[0];
+              } else {
+#pragma unroll
+                for (int e = 0; e < D * D; ++e) at(A.V, e, s)[tl] = Vn[e];
+                store_factor(s, Ln);
+              }
+            }
+          }
+          c.wn = 0;
+#pragma unroll
+          for (int p = 0; p < D; ++p) { c.wr[p] = c.q[p]; c.ws[p] = 0.0; }
+#pragma unroll
+          for (int e = 0; e < D * D; ++e) c.wq[e] = 0.0;
+        }
+        if (!kWinRegs) store_window(s, tl);
+      }
+    }
+  }
+
+#pragma unroll
+  for (int s = 0; s < NC; ++s) {
+    const Chain<D> &c = ch[s];
+    if (c.valid) {
+#pragma unroll
+      for (int p = 0; p < D; ++p) at(A.q, p, s)[t] = c.q[p];
+      if constexpr (D == 1) at(A.V, 0, s)[t] = c.V1;
+      at(A.ssq, 0, s)[t] = c.ssq;
+      at(A.std2, 0, s)[t] = c.std2;
+      if (kWinRegs && A.adapt_mode != RSF_ADAPT_NONE) store_window(s, t);
+    }
   }
   // statistics: wave shuffle reduction, one atomic per wave and counter
   const unsigned long long s0 = rsf::wave_sum(n_acc), s1 = rsf::wave_sum(n_eval), s2 = rsf::wave_sum(n_nonfinite);

@@ -762,6 +762,57 @@ def test_float32_solve_against_the_float32_restatement(pkg, oracle_lib, oracle_m
     assert e_traj.max() < 5e-6
 
 
+@pytest.mark.parametrize("d,C,groups", [(1, 1000, 1), (3, 777, 1), (1, 2048, 2)])
+def test_float32_sampler_two_chains_per_lane(pkg, oracle_lib, oracle_mod, d, C, groups):
+    """The float32 sampler carries TWO chains per lane (mcmc_f32x2_kernel: every instruction of its solve is a packed pair).
+    (a) Exactness of the packed form: after a run, the SSq the sampler holds for each chain's current point is BIT-identical
+    to what the one-chain float32 forward kernel computes for that point (same arithmetic, IEEE per half), chain counts that
+    leave the second slot partly / wholly empty, d = 1 and 3, one and two observation groups.  (b) The chains against the
+    float32 restatement run as a sampler on the CPU with the same Philox stream: accept decisions may differ only where
+    the two SSq — equal to ~3e-8 — straddle a decision, so at least 99.5 % of the chains must be identical in every decision,
+    and those agree in q to 1e-9 and in sigma^2 to 1e-6."""
+    rng = np.random.default_rng(100 + C)
+    m = _models(oracle_mod, 500)
+    m.precision = "float32"
+    q0 = np.column_stack([rng.uniform(500.0, 2500.0, C), rng.uniform(0.010, 0.012, C), rng.uniform(0.013, 0.015, C)])[:, :d]
+    lo, hi = [0.0, 0.005, 0.005][:d], [1.0e4, 0.02, 0.03][:d]
+    V0 = np.tile(np.diag(np.array([25.0 ** 2, 1e-4 ** 2, 1e-4 ** 2][:d])), (C, 1, 1))
+    n_iters = 12
+    with pkg.Engine(mem="host") as g, pkg.Engine(lib=oracle_lib) as c:
+        for e in (g, c):
+            e.set_model(m, 1)
+        m64 = _models(oracle_mod, 500)
+        with pkg.Engine(lib=oracle_lib) as c64:
+            c64.set_model(m64, 1)
+            base = synthetic_data(c64)
+        data = base if groups == 1 else np.stack([base, base * 1.1])
+        for e in (g, c):
+            # (d = 3 without adaptation: a covariance estimated from a 4-sample window in three dimensions is near-singular and
+            #  amplifies rounding differences of the host arithmetic into different proposals — not what this test is about)
+            e.mcmc_init(q0, data, lo, hi, seed=5, prior_len=3 if d == 1 else 0, adapt_mode="am" if d == 1 else "none", adapt_interval=4)
+        state0 = list(c.get_state())
+        state0[3] = V0
+        for e in (g, c):
+            e.set_state(*state0)
+        tg, tc = g.mcmc_run(n_iters), c.mcmc_run(n_iters)
+        # (a) the state's SSq is the float32 forward solve at the state's point, bit for bit
+        q, ssq, _, _ = g.get_state()
+        per = C // groups
+        for grp in range(groups):
+            sl = slice(grp * per, (grp + 1) * per)
+            f, _ = g.forward(q[sl, 0], a=q[sl, 1] if d == 3 else None, b=q[sl, 2] if d == 3 else None,
+                             data=data if groups == 1 else data[grp], want_ssq=True, want_acc=False)
+            moved = tg[2][:, sl].any(axis=0)  # chains that accepted at least once hold an SSq computed by the packed solve
+            assert moved.sum() > per // 2
+            np.testing.assert_array_equal(ssq[sl][moved], f[moved])
+    # (b) against the float32 restatement's chains
+    same = (tg[2] == tc[2]).all(axis=0)
+    print(f"float32 sampler vs float32 restatement: {int((~same).sum())} of {C} chains differ in a decision")
+    assert same.mean() >= 0.995
+    np.testing.assert_allclose(tg[0][:, same], tc[0][:, same], rtol=1e-9)
+    np.testing.assert_allclose(tg[1][:, same], tc[1][:, same], rtol=1e-6)
+
+
 def test_float32_tolerance_at_config5_shape():
     """BASELINE configs[4] per-GPU shard (131 072 chains, nsteps 4000, joint (Dc, a, b)) in BOTH precisions, same seeds —
     tools/fp32_sweep_cfg5.py with a shorter sampler run.  Bands (profiles/r02/fp32_sweep_cfg5.json holds the 400-iteration
