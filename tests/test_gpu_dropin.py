@@ -351,3 +351,23 @@ def test_public_submethods_compose_into_the_sample_loop_on_the_gpu(pkg, golden, 
     assert len(np.unique(qparams)) > 5
     np.testing.assert_allclose(qparams[:, mc.nburn:], q_fused, rtol=1e-9)
     np.testing.assert_allclose(std2[mc.nburn:], fused.std2, rtol=1e-9)
+
+
+def test_drop_in_sample_with_the_float32_solve(pkg, golden):
+    """`RateStateModel.precision = "float32"` under the drop-in single-chain `MCMC.sample()`: one chain is one half-filled
+    lane of the two-chains-per-lane float32 sampler, driven through the one-proposal replay graph.  Same seed, same
+    variates: the float32 chain follows the float64 one until a decision falls inside the ~1e-4 SSq difference."""
+    g = golden.npz("ssq")
+    out = {}
+    for precision in ("float64", "float32"):
+        model = pkg.RateStateModel(number_time_steps=500)
+        model.precision = precision
+        np.random.seed(23)
+        mc = pkg.MCMC(model, g["data"], 1000.0, ["Uniform", 0.0, 1e4], 1000.0, nsamples=60, lstm_model=None, verbose=False)
+        out[precision] = (mc.sample(False), mc.std2, mc.acceptance_ratio)
+    q64, q32 = out["float64"][0], out["float32"][0]
+    assert q32.shape == q64.shape == (1, 31) and np.isfinite(q32).all()
+    assert abs(out["float32"][2] - out["float64"][2]) <= 0.1
+    same = np.isclose(q32, q64, rtol=1e-6)
+    assert same[0, :5].all() or same.mean() > 0.5, (q32[0, :8], q64[0, :8])
+    np.testing.assert_allclose(out["float32"][1][:3], out["float64"][1][:3], rtol=1e-3)

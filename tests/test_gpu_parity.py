@@ -447,6 +447,25 @@ def test_edge_cases_and_call_order(pkg, cpu_engine, oracle_mod):
             ref = ref or out
             for k in range(3):
                 np.testing.assert_array_equal(out[k], ref[k])
+    # ... the three-parameter kernel (Cholesky factors in LDS behind the table chunk) and the float32 sampler, whose lanes
+    # carry two chains each (slot layout, LDS factor slots and grid all depend on the workgroup size)
+    q3 = np.column_stack([np.linspace(600.0, 2400.0, 333), np.full(333, 0.011), np.full(333, 0.014)])
+    V3 = np.tile(np.diag([25.0 ** 2, 1e-4 ** 2, 1e-4 ** 2]), (333, 1, 1))
+    for precision, d in (("float64", 3), ("float32", 1), ("float32", 3)):
+        m2 = _models(oracle_mod, 500)
+        m2.precision = precision
+        ref = None
+        for block in (64, 128, 256):
+            with pkg.Engine(mem="host", block_threads=block) as e:
+                e.set_model(m2, 1)
+                e.mcmc_init(q3[:, :d], data, [0.0, 0.005, 0.005][:d], [1e4, 0.02, 0.03][:d], seed=4, prior_len=3 if d == 1 else 0,
+                            adapt_mode="am", adapt_interval=4)
+                if d == 3:
+                    e.set_state(V=V3)
+                out = e.mcmc_run(9)
+                ref = ref or out
+                for k in range(3):
+                    np.testing.assert_array_equal(out[k], ref[k], err_msg=f"{precision} d={d} block={block}")
     with pytest.raises(pkg._abi.RsfError):
         pkg.Engine(mem="host", block_threads=96)
     with pkg.Engine(mem="host") as e:
