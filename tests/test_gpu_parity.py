@@ -832,6 +832,31 @@ def test_float32_sampler_two_chains_per_lane(pkg, oracle_lib, oracle_mod, d, C, 
     np.testing.assert_allclose(tg[1][:, same], tc[1][:, same], rtol=1e-6)
 
 
+def test_float32_sampler_is_exact_at_config5_shape(pkg, oracle_mod):
+    """The packed two-chains-per-lane solve at BASELINE configs[4]'s own per-GPU shape (131 072 chains, nsteps 4000, joint
+    (Dc, a, b): two LDS chunks per solve): after three proposals every chain's SSq is bit-identical to the one-chain float32
+    forward kernel at the chain's current point — 131 072 of 131 072."""
+    import torch
+
+    C, n = 131072, 4000
+    m = _models(oracle_mod, n)
+    m.precision = "float32"
+    rng = np.random.default_rng(9)
+    q0 = np.column_stack([rng.uniform(500.0, 2500.0, C), rng.uniform(0.010, 0.012, C), rng.uniform(0.013, 0.015, C)])
+    with pkg.Engine(mem="device") as e, pkg.Engine(mem="host") as h:
+        h.set_model(_models(oracle_mod, n), 1)
+        data = synthetic_data(h)
+        e.set_model(m, 1)
+        e.mcmc_init(q0, data, [0.0, 0.005, 0.005], [1.0e4, 0.02, 0.03], seed=11, adapt_mode="none")
+        e.set_state(V=torch.diag(torch.tensor([20.0 ** 2, 1e-4 ** 2, 1e-4 ** 2], dtype=torch.float64, device="cuda")).repeat(C, 1, 1))
+        _, _, ta = e.mcmc_run(3, traces=("accept",))
+        q, ssq, _, _ = e.get_state()
+        f, _ = e.forward(q[:, 0].contiguous(), a=q[:, 1].contiguous(), b=q[:, 2].contiguous(), data=data, want_ssq=True, want_acc=False)
+        e.sync()
+        assert float(ta.double().mean()) > 0.3 and bool(torch.isfinite(ssq).all())
+        assert bool(torch.equal(ssq, f)), int((ssq != f).sum())
+
+
 def test_float32_tolerance_at_config5_shape():
     """BASELINE configs[4] per-GPU shard (131 072 chains, nsteps 4000, joint (Dc, a, b)) in BOTH precisions, same seeds —
     tools/fp32_sweep_cfg5.py with a shorter sampler run.  Bands (profiles/r02/fp32_sweep_cfg5.json holds the 400-iteration
