@@ -10,5 +10,6 @@ KEYS = (("VGPR", r"VGPRs"), ("AGPR", r"AGPRs"), ("scratch", r"ScratchSize \[byte
 for b in re.split(r'remark: Function Name: ', txt)[1:]:
     name = b.split()[0]
     vals = " ".join("%s %4s" % (k, (re.search(pat + r": (\d+)", b) or [None, "?"])[1]) for k, pat in KEYS)
-    print("%-62s %s" % (name[15:75], vals))
+    name = re.sub(r"^_ZN4rsfk\d+", "", name)  # kernels live in namespace rsfk
+    print("%-62s %s" % (name[:62], vals))
 PY
