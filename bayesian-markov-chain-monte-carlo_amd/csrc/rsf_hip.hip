@@ -184,8 +184,18 @@ int chains_per_lane(const rsf_ctx *c) { return mode_of(c) == RK4_F32 ? 2 : 1; }
 
 // LDS of a sampler launch: the table chunk, and behind it the per-lane Cholesky factors of a three-parameter chain
 // (six doubles per lane, mcmc_kernel)
+// the table chunk as the sampler kernel stages it: doubles, or floats in the float32 sampler (same chunk length kc: the
+// float64 init kernel of that mode stages the same chunks as doubles)
+size_t mcmc_table_bytes(const rsf_ctx *c) {
+  return mode_of(c) == RK4_F32 ? ((c->lds_bytes / 2 + 15) & ~(size_t)15) : c->lds_bytes;
+}
+
 size_t mcmc_lds_bytes(const rsf_ctx *c) {
-  return c->lds_bytes + (c->mc.n_params == 3 ? (size_t)6 * sizeof(double) * (size_t)c->block * (size_t)chains_per_lane(c) : 0);
+  if (c->mc.n_params != 3) return mcmc_table_bytes(c);
+  // per lane: the six doubles of a chain's Cholesky factor (two chains in the float32 sampler); the float64 RK4 sampler
+  // also parks the chain's point, sigma^2 and SSq there across the forward solve (five more)
+  const size_t slots = mode_of(c) == RK4_F32 ? 12 : (mode_of(c) == RK4_F64 ? 11 : 6);
+  return mcmc_table_bytes(c) + slots * sizeof(double) * (size_t)c->block;
 }
 
 // workgroups of a sampler launch over n chains
@@ -391,7 +401,7 @@ int run_mcmc(rsf_ctx *c, int64_t n_iters, const double *z, const double *u, cons
   for (int p = 0; p < RSF_MAX_PARAMS; ++p) { A.lo[p] = c->mc.lo[p]; A.hi[p] = c->mc.hi[p]; }
   A.adapt_mode = c->mc.adapt_mode; A.adapt_interval = c->mc.adapt_interval > 0 ? c->mc.adapt_interval : 1;
   A.dict_scale = 2.38 * 2.38 / (double)(c->mc.prior_len > 0 ? c->mc.prior_len : 2);
-  A.lc_off = (int32_t)(c->lds_bytes / sizeof(double));
+  A.lc_off = (int32_t)(mcmc_table_bytes(c) / sizeof(double));
   A.q = (double *)c->q.p; A.ssq = (double *)c->ssq.p; A.std2 = (double *)c->std2.p; A.V = (double *)c->V.p;
   A.wref = (double *)c->wref.p; A.wsum = (double *)c->wsum.p; A.wsq = (double *)c->wsq.p; A.wn = (int32_t *)c->wn.p;
   A.stats = (unsigned long long *)c->stats.p;

@@ -38,10 +38,11 @@ constexpr int kMinBlocks = 2;
 // three-parameter sampler: TIGHT loop trips of kD3Trip * kTightUnroll steps like the one-parameter sampler's 2 * (+2.3 %
 // over 1 at 131 072 chains x nsteps 4000; the few spills it costs all lie outside the loops)
 constexpr int kD3Trip = 2;
-// LDS per workgroup for the loading table + observation chunk.  Two workgroups per CU (kMinBlocks) at 64 KiB each fit the
-// CU's 160 KiB next to the three-parameter sampler's 12 KiB of Cholesky factors; nsteps 2000 (48 KB) then stays resident
-// for the whole launch instead of being staged twice per proposal (+1.3 % at cfg2).
-constexpr size_t kLdsBudget = 64 * 1024;
+// LDS per workgroup for the loading table + observation chunk.  Two workgroups per CU (kMinBlocks) at 56 KiB each fit the
+// CU's 160 KiB next to the three-parameter samplers' per-lane slots (up to 24 KiB: Cholesky factors, parked chain state);
+// nsteps 2000 (48 KB) stays resident for the whole launch instead of being staged twice per proposal (+1.3 % at cfg2), and so
+// does nsteps 4000 of the float32 solve, whose tables are floats.
+constexpr size_t kLdsBudget = 56 * 1024;
 
 // ---------------------------------------------------------------------------------------------
 // kernels
@@ -453,6 +454,15 @@ __global__ void __launch_bounds__(kMaxBlock, kMinBlocks) mcmc_kernel(Consts K, M
     }
 #pragma unroll
     for (int p = 0; p < D; ++p) inb = inb && (qn[p] > A.lo[p]) && (qn[p] < A.hi[p]);  // strict box, MCMC.py:318-320
+    // D = 3: the chain's current point, sigma^2 and SSq wait out the forward solve in LDS (five slots per lane behind the Cholesky
+    // factor) instead of in ten registers the integrator needs — the three spills per proposal this kernel had otherwise
+    constexpr bool kPark = D == 3 && MODE == RK4_F64;  // (the DOP853 kernel allocates worse with it: measured, tools/one_kernel.sh)
+    if constexpr (kPark) {
+#pragma unroll
+      for (int p = 0; p < D; ++p) lcs[(6 + p) * blockDim.x] = q[p];
+      lcs[9 * blockDim.x] = std2;
+      lcs[10 * blockDim.x] = ssq;
+    }
     // ---- likelihood: forward solve only for in-bounds proposals, MCMC.py:322-324 ----
     double an = K.a_def, bn = K.b_def;
     if constexpr (D == 3) { an = qn[1]; bn = qn[2]; }
@@ -461,6 +471,14 @@ __global__ void __launch_bounds__(kMaxBlock, kMinBlocks) mcmc_kernel(Consts K, M
     if (!resident || __any(inb)) {
       if constexpr (MODE == DOP853) ssqn = rsf::dp::solve<DAMP, true, false>(lds, K, resident, inb, qn[0], an, bn, nullptr, 0);
       else ssqn = rsf::solve<DAMP, true, false, (D == 1 ? 2 : kD3Trip) * rsf::kTightUnroll>(lds, K, resident, inb, qn[0], an, bn, nullptr, 0);
+    }
+    if constexpr (kPark) {
+      const double *back = lcs;
+      asm volatile("" : "+v"(back));  // opaque: the values are re-read, not carried across the solve
+#pragma unroll
+      for (int p = 0; p < D; ++p) q[p] = back[(6 + p) * blockDim.x];
+      std2 = back[9 * blockDim.x];
+      ssq = back[10 * blockDim.x];
     }
     // ---- accept / reject, MCMC.py:327-333 ----
     bool accept = false;
