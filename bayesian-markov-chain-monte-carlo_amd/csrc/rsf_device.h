@@ -58,7 +58,6 @@ struct Lane {
   // g, i.e. on dV/dt in units of vk per unit w — vk multiplies only the finished sample (cv), not every stage
   double vk;      // (V_ref/a) k'
   double beta;    // (b/theta dtheta/dt)/(k' d(ms)/dt) coefficient: (V_ref b/Dc)/k' = 10 b V_ref (independent of Dc)
-  double c3;      // beta - V_ref  : coefficient of w in g once d0 and d1/x are written out (rhs_fast)
   double kvk;     // (k1/k') vk = k1 V_ref/a : radiation damping, d0 -= kvk w g
   double cv;      // cacc vk       : acceleration sample = cv * (g-weighted RK4 sum of the step)
   double h6v;     // (h/6) vk      : velocity increment of a step = h6v * that sum
@@ -87,7 +86,6 @@ __device__ __forceinline__ Lane make_lane(double dc, double a, double b, const C
   L.vdc = K.V_ref * L.inv_dc;
   L.vk = via * L.kprime;
   L.beta = (b * K.V_ref) * (1.0 / (1e-2 * 10));
-  L.c3 = L.beta - K.V_ref;
   L.kvk = K.k1 * via;
   L.cv = K.cacc * L.vk;
   L.h6v = K.h6 * L.vk;
@@ -128,19 +126,21 @@ __device__ __forceinline__ void rhs_tail(double w, double rx, double x, double v
   d2 = w * g;
 }
 
-// The same RHS arranged for the hot loop, where w arrives last (it ends the dependency chain of the previous stage):
-// with d1/x = 1/x - w the bracket g of dV/dt = vk w g is LINEAR in w,
-//     g = (V_l - V_ref w) - beta (1/x - w) = (V_l - beta/x) + (beta - V_ref) w,
-// so everything but one fma is ready before w is, and the damped d0 follows two instructions after w instead of
-// five.  (beta/x and beta w nearly cancel, but against V_l their rounding is ~3e-17 of the result.)  Working on g rather
+// The same RHS arranged for the hot loop, with the caller supplying brx = beta/x at the stage point: the bracket of
+// dV/dt = vk w g is  g = d0 - (beta/x) d1  — one fma on the two derivatives the stage forms anyway.  Working on g rather
 // than on vk g makes the damping pass ONE product shared by both corrections: d0 -= (kvk w) g and g -= (kvk w) g.
 // The caller forms w g (the stage's dV/dt in units of vk) inside its weighted sum.
+// (Rounds 1-2 wrote g = (V_l - beta/x) + (beta - V_ref) w, linear in w, so that all but one fma was ready before w — the
+// end of the previous stage's dependency chain — arrived: one instruction more per stage for one dependent level less.
+// Measured in round 3 (profiles/r03/ab_gform.log) the shorter instruction stream wins at every shape, also at cfg1's one
+// wave per SIMD: +2.1 % cfg1, +3.0 % cfg2, +2.5 % d = 3.  The rounding is the same: d1 = 1 - w x comes out of one fma with
+// an absolute error of 1e-16, which beta/x ~ 0.14 scales to 2e-17 of g.)
 template <bool DAMP>
-__device__ __forceinline__ void rhs_fast(double w, double x, double vl, double t1, const Lane &L, const Consts &K, double &d0,
-                                         double &d1, double &g) {  // t1 = V_l - beta/x, formed by the caller (no w in it)
+__device__ __forceinline__ void rhs_fast(double w, double x, double vl, double brx, const Lane &L, const Consts &K, double &d0,
+                                         double &d1, double &g) {
   d1 = __builtin_fma(-w, x, 1.0);
   d0 = __builtin_fma(-K.V_ref, w, vl);
-  g = __builtin_fma(L.c3, w, t1);
+  g = __builtin_fma(-brx, d1, d0);
   if (DAMP) {
     const double kw = L.kvk * w;
     d0 = __builtin_fma(-kw, g, d0);
@@ -172,12 +172,12 @@ __device__ __forceinline__ void eval_full(double ms, double x, const Lane &L, co
 // result and the loop branch: +3 % at cfg1.)
 enum Tier : int { TIGHT = 0, NARROW = 1, WIDE = 2 };
 
-// t1 of a stage.  TIGHT stages never form 1/x at the stage point: with 1/x' = (1/x)(1 + q), q = rho^2 - rho (eval_incr
+// beta/x of a stage.  TIGHT stages never form 1/x at the stage point: with 1/x' = (1/x)(1 + q), q = rho^2 - rho (eval_incr
 // hands q back in place of 1/x'), beta/x' = br0 + br0 q where br0 = beta/x at the step's start.
 template <int T>
-__device__ __forceinline__ double stage_t1(double vl, double rx_or_q, double br0, const Lane &L) {
-  if (T == TIGHT) return __builtin_fma(-br0, rx_or_q, vl - br0);
-  return __builtin_fma(-L.beta, rx_or_q, vl);
+__device__ __forceinline__ double stage_brx(double rx_or_q, double br0, const Lane &L) {
+  if (T == TIGHT) return __builtin_fma(br0, rx_or_q, br0);
+  return L.beta * rx_or_q;
 }
 
 struct Guard {
@@ -200,7 +200,7 @@ __device__ __forceinline__ void set_tier(Lane &L) {
 
 template <int T, bool STAGE, bool HALF = false>
 __device__ __forceinline__ void eval_incr(double kf, double dms_dt, double R, double dth_dt, double x1, const Lane &L, double w0,
-                                          double rx0, double &w, double &rx, Guard &g) {  // TIGHT && STAGE: rx returns q (stage_t1)
+                                          double rx0, double &w, double &rx, Guard &g) {  // TIGHT && STAGE: rx returns q (stage_brx)
   // dk = kf * dms_dt (kf: kia times the step fraction);  rho = R * dth_dt (R: step fraction / Dc / x, once per step)
   const double rho = dth_dt * R;
   g.rho = __builtin_fmaxf(g.rho, __builtin_fabsf(hi_as_float(rho)));
@@ -304,19 +304,19 @@ __device__ __forceinline__ double rk4_fast(State &s, double vl0, double vlm, dou
   double a0, a1, a2, b0, b1, b2, c0, c1, c2, e0, e1, e2, w, rx, xs;
   const double Rh = L.hhd * s.rx, Rf = Rh + Rh, R6 = L.h6d * s.rx;  // rho of a stage = its theta derivative times these
   const double br0 = L.beta * s.rx;
-  rhs_fast<DAMP>(s.w, s.x, vl0, vl0 - br0, L, K, a0, a1, a2);
+  rhs_fast<DAMP>(s.w, s.x, vl0, br0, L, K, a0, a1, a2);
   double sv = s.w * a2;  // k1 + k4 of dV/dt (in units of vk), and k2 + k3 below: 5 instructions for the weighted sum
   xs = __builtin_fma(L.hhd, a1, s.x);
   eval_incr<T, true, true>(L.khh, a0, Rh, a1, xs, L, s.w, s.rx, w, rx, g);
-  rhs_fast<DAMP>(w, xs, vlm, stage_t1<T>(vlm, rx, br0, L), L, K, b0, b1, b2);
+  rhs_fast<DAMP>(w, xs, vlm, stage_brx<T>(rx, br0, L), L, K, b0, b1, b2);
   double sm = w * b2;
   xs = __builtin_fma(L.hhd, b1, s.x);
   eval_incr<T, true, true>(L.khh, b0, Rh, b1, xs, L, s.w, s.rx, w, rx, g);
-  rhs_fast<DAMP>(w, xs, vlm, stage_t1<T>(vlm, rx, br0, L), L, K, c0, c1, c2);
+  rhs_fast<DAMP>(w, xs, vlm, stage_brx<T>(rx, br0, L), L, K, c0, c1, c2);
   sm = __builtin_fma(w, c2, sm);
   xs = __builtin_fma(L.hd, c1, s.x);
   eval_incr<T, true>(L.kh, c0, Rf, c1, xs, L, s.w, s.rx, w, rx, g);
-  rhs_fast<DAMP>(w, xs, vl1, stage_t1<T>(vl1, rx, br0, L), L, K, e0, e1, e2);
+  rhs_fast<DAMP>(w, xs, vl1, stage_brx<T>(rx, br0, L), L, K, e0, e1, e2);
   sv = __builtin_fma(w, e2, sv);
   const double t0 = a0 + 2.0 * b0 + 2.0 * c0 + e0;
   const double t1 = a1 + 2.0 * b1 + 2.0 * c1 + e1;

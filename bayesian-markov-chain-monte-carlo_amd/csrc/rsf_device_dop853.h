@@ -35,7 +35,7 @@ constexpr double kBhh1 = 0.244094488188976377952755905512, kBhh2 = 0.73384668828
 
 struct LaneD {
   double inv_dc, kprime, inv_a, b;
-  double boa, c3;  // b/a and b/Dc - k': the fast path's folded constants (FastStep)
+  double boa;  // b/a: the fast path's folded constant (FastStep)
 };
 
 // loading velocity V_l(t) = V_ref (1 + exp(-t/20) sin(10 t)), RateStateModel.py:327-329, at a time that is not in the
@@ -103,11 +103,9 @@ struct GuardD {
 // FastStep holds what a step's twelve incremental evaluations share, so that a stage costs ~25 instructions instead of
 // ~30: with sm / sth the stage's tableau sums of the mu / theta derivatives,
 //     rho = (h/theta_0) sth        theta_s/Dc = theta_0/Dc + (h/Dc) sth        dlt = (h/a) sm - (b/a) log1p(rho),
-// and the bracket of dV/dt = (v/a)(dmu/dt - (b/theta) dtheta/dt), g = k'(V_l - v) - (b/theta_s)(1 - v theta_s/Dc), is LINEAR
-// in v once (1/theta_s)(theta_s/Dc) = 1/Dc is used:   g = (k' V_l - b/theta_s) + (b/Dc - k') v,   b/theta_s = (b/theta_0)(1 + q)
-// (b/theta_s and (b/Dc) v nearly cancel near steady state; against k' V_l their rounding is ~1e-17 of g — the same
-// regrouping as rsf_device.h's rhs_fast).  The damping pass (RateStateModel.py:349-353) subtracts the same k1 dV/dt from
-// dmu/dt and from g.
+// and the bracket of dV/dt = (v/a)(dmu/dt - (b/theta) dtheta/dt) is one fma on the two derivatives the stage forms anyway,
+//     g = k'(V_l - v) - (b/theta_s)(1 - v theta_s/Dc),   b/theta_s = (b/theta_0)(1 + q)
+// (rsf_device.h's rhs_fast).  The damping pass (RateStateModel.py:349-353) subtracts the same k1 dV/dt from dmu/dt and from g.
 struct FastStep {
   double ha, hd, hr;   // h/a, h/Dc, h/theta_0
   double thd0, br0;    // theta_0/Dc, b/theta_0
@@ -140,7 +138,7 @@ __device__ __forceinline__ Deriv friction_incr(const Consts &K, const LaneD &L, 
   Deriv d;
   d.t = __builtin_fma(-v, __builtin_fma(F.hd, sth, F.thd0), 1.0);       // 1 - v theta_s / Dc
   d.m = __builtin_fma(-L.kprime, v, kvl);                                // k' (V_l - v)
-  double gg = __builtin_fma(L.c3, v, __builtin_fma(-F.br0, q, kvl - F.br0));
+  double gg = __builtin_fma(-__builtin_fma(F.br0, q, F.br0), d.t, d.m);    // k'(V_l - v) - (b/theta_s)(1 - v theta_s/Dc)
   const double va = v * L.inv_a;
   d.v = va * gg;
   if (DAMP) {
@@ -396,7 +394,7 @@ __device__ __forceinline__ void stage_chunk_dp(double *lds, const Consts &K, int
 __device__ __forceinline__ LaneD make_lane_dp(double dc, double a, double b) {
   LaneD L;
   L.inv_dc = 1.0 / dc; L.kprime = (1e-2 * 10) / dc; L.inv_a = 1.0 / a; L.b = b;
-  L.boa = b * L.inv_a; L.c3 = b * L.inv_dc - L.kprime;
+  L.boa = b * L.inv_a;
   return L;
 }
 
