@@ -64,6 +64,7 @@ struct Lane {
   double boa;     // b/a
   double tc;      // -mu_ref/a
   double hhd, hd, h6d;  // (h/2)/Dc, h/Dc, (h/6)/Dc : theta increments in x units
+  double inv_hhd, bh;   // 1/hhd and beta/hhd: the TIGHT tier carries hhd/x in place of 1/x (rk4_fast)
   double c_l1p;   // leading series coefficients of the active tier, kept in VGPRs (a VOP3 takes one SGPR source and
   double c_em1;   //   the first Horner term has two non-inline constants); see set_tier
   double c_em1h;  // TIGHT half-step stages: 1/24
@@ -94,6 +95,8 @@ __device__ __forceinline__ Lane make_lane(double dc, double a, double b, const C
   L.hhd = K.hh * L.vdc;
   L.hd = K.h * L.vdc;
   L.h6d = K.h6 * L.vdc;
+  L.inv_hhd = fm::rcp(L.hhd);
+  L.bh = L.beta * L.inv_hhd;
   set_tier<2>(L);
   return L;
 }
@@ -106,6 +109,9 @@ __device__ __forceinline__ Lane make_lane(double dc, double a, double b, const C
 
 // Integration state of one lane: ms = mu/k', x = V_ref theta/Dc, V, and the transcendental parts of the RHS at
 // that point:  w = v/V_ref = exp(mu/a - mu_ref/a - (b/a) log x),   rx = 1/x.
+// INSIDE the TIGHT tier's loops rx holds hhd/x instead (tier_enter / tier_leave): what a step needs of 1/x are the three
+// multiples (h/2Dc)/x, (h/6Dc)/x and beta/x, and the step-end update 1/x' = (1/x)(1 + q) is indifferent to a constant
+// factor — carrying the first multiple makes it free and the other two one product each (-1 instruction per step).
 struct State {
   double ms, x, V;
   double w, rx;
@@ -152,6 +158,17 @@ __device__ __forceinline__ void rhs_fast(double w, double x, double vl, double b
 __device__ __forceinline__ void eval_full(double ms, double x, const Lane &L, const Consts &K, double &w, double &rx) {
   w = fm::exp(__builtin_fma(-L.boa, fm::log(x), __builtin_fma(ms, L.kia, L.tc)));
   rx = fm::rcp(x);
+}
+
+// the TIGHT tier's representation of 1/x (struct State)
+template <int T>
+__device__ __forceinline__ void tier_enter(State &s, const Lane &L) { if (T == 0) s.rx *= L.hhd; }
+template <int T>
+__device__ __forceinline__ void tier_leave(State &s, const Lane &L) { if (T == 0) s.rx *= L.inv_hhd; }
+template <int T>
+__device__ __forceinline__ void eval_full_t(State &s, const Lane &L, const Consts &K) {
+  eval_full(s.ms, s.x, L, K, s.w, s.rx);
+  tier_enter<T>(s, L);
 }
 
 // (w', 1/x') at (ms + dms, x1 = x + dx) from (w, rx) at (ms, x).  With rho = dx/x (= dtheta/theta) and
@@ -302,8 +319,9 @@ template <bool DAMP, int T>
 __device__ __forceinline__ double rk4_fast(State &s, double vl0, double vlm, double vl1, const Lane &L,
                                            const Consts &K, Guard &g) {
   double a0, a1, a2, b0, b1, b2, c0, c1, c2, e0, e1, e2, w, rx, xs;
-  const double Rh = L.hhd * s.rx, Rf = Rh + Rh, R6 = L.h6d * s.rx;  // rho of a stage = its theta derivative times these
-  const double br0 = L.beta * s.rx;
+  // rho of a stage = its theta derivative times Rh / Rf / R6;  br0 = beta/x at the step's start  (TIGHT: s.rx is hhd/x)
+  const double Rh = T == TIGHT ? s.rx : L.hhd * s.rx, Rf = Rh + Rh, R6 = T == TIGHT ? s.rx * (1.0 / 3.0) : L.h6d * s.rx;
+  const double br0 = T == TIGHT ? L.bh * s.rx : L.beta * s.rx;
   rhs_fast<DAMP>(s.w, s.x, vl0, br0, L, K, a0, a1, a2);
   double sv = s.w * a2;  // k1 + k4 of dV/dt (in units of vk), and k2 + k3 below: 5 instructions for the weighted sum
   xs = __builtin_fma(L.hhd, a1, s.x);
@@ -412,8 +430,9 @@ __device__ __forceinline__ bool trip_fast(const double *v, const Lane &L, const 
   return !guard_ok<T>(g);
 }
 
-// the same trip with a full evaluation at every stage (exact whatever the increments), (w, 1/x) re-formed at its end
-template <bool DAMP, int NU>
+// the same trip with a full evaluation at every stage (exact whatever the increments), (w, 1/x) re-formed at its end in
+// tier T's representation
+template <bool DAMP, int T, int NU>
 __device__ __forceinline__ void trip_cold(const double *v, const Lane &L, const Consts &K, State &s, double (&dv)[NU]) {
 #pragma unroll 1
   for (int j = 0; j < NU; ++j) {  // one copy of the cold step; its result goes to dv[j] by selects, so that dv stays in registers
@@ -421,7 +440,7 @@ __device__ __forceinline__ void trip_cold(const double *v, const Lane &L, const 
 #pragma unroll
     for (int m = 0; m < NU; ++m) dv[m] = m == j ? r : dv[m];
   }
-  eval_full(s.ms, s.x, L, K, s.w, s.rx);
+  eval_full_t<T>(s, L, K);
 }
 
 // integrates RK4 steps [r, nsteps) of the chunk two at a time; returns the first step not yet integrated
@@ -433,7 +452,7 @@ __device__ __forceinline__ int integrate_pairs(const double *lds, const double *
     const double *v = lds + 2 * r;
     // observations this pair can complete, read before the arithmetic (S > 1: at most one sample per pair)
     const double obs0 = WANT_SSQ ? ld[S1 ? r : em.ko] : 0.0, obs1 = (WANT_SSQ && S1) ? ld[r + 1] : 0.0;
-    if ((r & (kResync - 1)) == 0) eval_full(s.ms, s.x, L, K, s.w, s.rx);
+    if ((r & (kResync - 1)) == 0) eval_full_t<T>(s, L, K);
     const State save = s;
     double dv[2];
     const bool bad = trip_fast<DAMP, T, 2>(v, L, K, s, dv);
@@ -441,7 +460,7 @@ __device__ __forceinline__ int integrate_pairs(const double *lds, const double *
     if (__builtin_expect(badmask != 0, 0)) {  // scalar branch: the hot path carries no exec-mask bookkeeping
       if (bad) {
         s = save;
-        trip_cold<DAMP, 2>(v, L, K, s, dv);
+        trip_cold<DAMP, T, 2>(v, L, K, s, dv);
       }
     }
     if (S1) {  // sample index == step index: no bookkeeping, and V is not carried at all
@@ -479,14 +498,14 @@ __device__ __forceinline__ int integrate_multi(const double *lds, const double *
     double obs[NO], dv[NU];
 #pragma unroll
     for (int j = 0; j < NO; ++j) obs[j] = WANT_SSQ ? ld[S1 ? r + j : min(em.ko + j, kn - 1)] : 0.0;
-    if ((r & (kResync - 1)) == 0) eval_full(s.ms, s.x, L, K, s.w, s.rx);
+    if ((r & (kResync - 1)) == 0) eval_full_t<T>(s, L, K);
     const State save = s;
     const bool bad = trip_fast<DAMP, T, NU>(v, L, K, s, dv);
     const unsigned long long badmask = __builtin_amdgcn_ballot_w64(bad);  // wave-uniform, straight from the compares
     if (__builtin_expect(badmask != 0, 0)) {  // scalar branch: the hot path carries no exec-mask bookkeeping
       if (bad) {
         s = save;
-        trip_cold<DAMP, NU>(v, L, K, s, dv);
+        trip_cold<DAMP, T, NU>(v, L, K, s, dv);
       }
     }
     if (S1) {
@@ -532,8 +551,10 @@ __device__ __forceinline__ void integrate_tiers(const double *lds, const double 
   // `t_trip` / `n_trip`: that tier's guard tripped in the long-trip loop, the rest goes to the next wider tier
   bool t_trip = false, n_trip = false, unused = false;
   if (tier == TIGHT) {
+    tier_enter<TIGHT>(s, L);
     r = integrate_multi<DAMP, WANT_SSQ, WANT_ACC, TIGHT, S1, NUT>(lds, ld, K, L, k0, kn, r, nsteps, s, em, ssq, acc_out, stride, t_trip);
     if (!t_trip) r = integrate_pairs<DAMP, WANT_SSQ, WANT_ACC, TIGHT, S1>(lds, ld, K, L, k0, r, nsteps, s, em, ssq, acc_out, stride);
+    tier_leave<TIGHT>(s, L);
   }
   if (tier <= NARROW) {
     r = integrate_multi<DAMP, WANT_SSQ, WANT_ACC, NARROW, S1, kWiderUnroll>(lds, ld, K, L, k0, kn, r, nsteps, s, em, ssq, acc_out, stride, n_trip);
@@ -550,7 +571,7 @@ __device__ __forceinline__ void integrate_tiers(const double *lds, const double 
     double dv[1];
     if (__builtin_expect(trip_fast<DAMP, WIDE, 1>(v, Lw, K, s, dv), 0)) {
       s = save;
-      trip_cold<DAMP, 1>(v, L, K, s, dv);
+      trip_cold<DAMP, WIDE, 1>(v, L, K, s, dv);
     }
     if (S1) {
       emit_incr<WANT_SSQ, WANT_ACC>(dv[0], kn - 1, obs, L, k0, ssq, acc_out, stride);

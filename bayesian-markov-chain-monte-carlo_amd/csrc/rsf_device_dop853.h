@@ -20,6 +20,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "../../include/rsf_dop853_tableau.h"
 #include "rsf_device.h"
 
@@ -32,6 +34,52 @@ constexpr double kRtol = 1e-6, kAtol = 1e-10;
 constexpr double kBhh1 = 0.244094488188976377952755905512, kBhh2 = 0.733846688281611857341361741547,
                  kBhh3 = 0.0220588235294117647058823529412;
 // (tests/test_oracle_golden.py::test_dop853_bhh_constants checks them against the tableau's E3)
+
+// The fast path's copy of the tableau, in constant memory, one packed row per stage: the non-zero A_st,j in column
+// order, then (stages with weight in the closing sums) B_st and E5_st; the last row holds the closing sums' own
+// {B, E5} pairs and bhh.  As literals the ~75 constants of a step were 150 s_mov_b32 per interval — and an instruction
+// of any kind costs its wave one issue turn (every 4th cycle), so a wave spent 16 % of its cycles materialising
+// constants.  From here a stage's row arrives in one or two s_load_dwordx8/x16 (scalar data cache), requested one
+// stage ahead — between two `pin`s, which fence the instruction scheduler — and from a base the compiler cannot see through
+// (`row_of`, once per step): hoisted to the kernel's entry instead, the loads held 150 SGPRs for the whole kernel
+// and spilled to VGPR lanes; sunk to their uses, each was an exposed scalar-cache latency.
+constexpr int kRowLen = 12, kClosingLen = 19;
+struct alignas(64) StepTable {
+  double a[11][kRowLen];
+  double w[8][2];
+  double bhh[4];
+};
+constexpr StepTable make_step_table() {
+  StepTable t{};
+  for (int i = 0; i < 11; ++i) {
+    int n = 0;
+    for (int j = 0; j <= i; ++j)
+      if (RSF_DP_A[i][j] != 0.0) t.a[i][n++] = RSF_DP_A[i][j];
+    if (i + 1 >= 5) { t.a[i][n++] = RSF_DP_B[i + 1 - 4]; t.a[i][n++] = RSF_DP_E5[i + 1 - 4]; }
+  }
+  for (int j = 0; j < 8; ++j) { t.w[j][0] = RSF_DP_B[j]; t.w[j][1] = RSF_DP_E5[j]; }
+  t.bhh[0] = kBhh1; t.bhh[1] = kBhh2; t.bhh[2] = kBhh3;
+  return t;
+}
+constexpr StepTable kStepTable0 = make_step_table();
+__constant__ StepTable kStepTable = kStepTable0;
+typedef const double __attribute__((address_space(4))) *ConstRow;
+__device__ __forceinline__ ConstRow row_of(const double *p) {
+  ConstRow r = (ConstRow)p;
+  asm volatile("" : "+s"(r));
+  return r;
+}
+template <int N>
+__device__ __forceinline__ void pin(double (&c)[N], int n) {  // the first n values are in scalar registers from here on
+#pragma unroll
+  for (int i = 0; i < N; ++i)
+    if (i < n) asm volatile("" : "+s"(c[i]));
+}
+constexpr int row_len(int st) {  // stage st (0-based, 1..11): its non-zero A entries + {B, E5} where it carries weight
+  int n = st >= 5 ? 2 : 0;
+  for (int j = 0; j < st; ++j) n += RSF_DP_A[st - 1][j] != 0.0;
+  return n;
+}
 
 struct LaneD {
   double inv_dc, kprime, inv_a, b;
@@ -186,20 +234,34 @@ struct VSums {
   double k1, k9, k12;    // the three stage values the 3rd-order estimator subtracts (kBhh)
 };
 
-// The eleven inner stages of one step of size h from (x, y; first-stage derivative km[0], kt[0], vs.k1; b0).
-//   FAST   the tabulated standard step, stages evaluated incrementally (the steady state of call());
-//          → whether the lane's increments left the series' range (its values are then not to be used)
-//   !FAST  any step, every stage evaluated in full (`standard`: the loading table applies); → false
-// Both are straight-line code (eleven unrolled stages): that keeps the km / kt arrays in registers.  There is deliberately
-// no third, "incremental with longer series" variant for the general loop: the loop body would then hold two unrolled
-// stage blocks, and the sampler kernel no longer fits two waves per SIMD without spilling (measured: 128-364 B of
-// scratch per lane); the general loop runs for the first interval of a solve (HINIT), after a rejected step, and for
-// waves that hold a stiff small-Dc lane.
-template <bool DAMP, bool FAST>
-__device__ __forceinline__ bool stages(const Consts &K, const LaneD &L, const double *tab, bool standard, double x, double h,
-                                       const double y[3], double (&km)[12], double (&kt)[12], const Base &b0, VSums &vs) {
-  GuardD g = {0.0f, 0.0f};
-  const FastStep F = fast_step(L, h, y[1], b0);
+// compile-time loop: f(std::integral_constant<int, I>) for I in [I0, I1)
+template <int I0, int I1, class F>
+__device__ __forceinline__ void static_for(F &&f) {
+  if constexpr (I0 < I1) {
+    f(std::integral_constant<int, I0>{});
+    static_for<I0 + 1, I1>(f);
+  }
+}
+constexpr int nz_count(int st) {  // non-zero A entries of stage st (0-based, 1..11)
+  int n = 0;
+  for (int j = 0; j < st; ++j) n += RSF_DP_A[st - 1][j] != 0.0;
+  return n;
+}
+constexpr int nz_col(int st, int n) {  // column of the n-th of them
+  for (int j = 0; j < st; ++j)
+    if (RSF_DP_A[st - 1][j] != 0.0 && n-- == 0) return j;
+  return -1;
+}
+
+// The eleven inner stages of one step of size h from (x, y; first-stage derivative km[0], kt[0], vs.k1), every stage
+// evaluated in full (`standard`: the loading table applies): the general loop's form — HINIT's first interval, steps
+// after a rejection, waves that hold a stiff small-Dc lane.  Straight-line code (eleven unrolled stages): that keeps the
+// km / kt arrays in registers.  There is deliberately no "incremental with longer series" variant for the general loop:
+// the loop body would then hold two unrolled stage blocks, and the sampler kernel no longer fits two waves per SIMD
+// without spilling (measured: 128-364 B of scratch per lane).
+template <bool DAMP>
+__device__ __forceinline__ void stages_full(const Consts &K, const LaneD &L, const double *tab, bool standard, double x, double h,
+                                            const double y[3], double (&km)[12], double (&kt)[12], VSums &vs) {
   vs.s = RSF_DP_B[0] * vs.k1;
   vs.e5 = RSF_DP_E5[0] * vs.k1;
 #pragma unroll
@@ -211,27 +273,138 @@ __device__ __forceinline__ bool stages(const Consts &K, const LaneD &L, const do
         sm += RSF_DP_A[st - 1][j] * km[j];
         sth += RSF_DP_A[st - 1][j] * kt[j];
       }
-    const double vl = (FAST || standard) ? tab[st] : loading(K, st == 11 ? x + h : x + RSF_DP_C[st] * h);
-    const bool want_v = st >= 5;  // stages 6..12 (1-based) carry weight in the closing sums
-    Deriv d;
-    if (!FAST) {
-      Base unused;
-      d = friction<DAMP>(K, L, vl, y[0] + h * sm, y[1] + h * sth, unused);
-    } else if (want_v) {
-      d = friction_incr<DAMP, true>(K, L, F, vl, b0, sm, sth, g);
-    } else {
-      d = friction_incr<DAMP, false>(K, L, F, vl, b0, sm, sth, g);
-    }
+    const double vl = standard ? tab[st] : loading(K, st == 11 ? x + h : x + RSF_DP_C[st] * h);
+    Base unused;
+    const Deriv d = friction<DAMP>(K, L, vl, y[0] + h * sm, y[1] + h * sth, unused);
     km[st] = d.m;
     kt[st] = d.t;
-    if (want_v) {
+    if (st >= 5) {  // stages 6..12 (1-based) carry weight in the closing sums
       vs.s = __builtin_fma(RSF_DP_B[st - 4], d.v, vs.s);
       vs.e5 = __builtin_fma(RSF_DP_E5[st - 4], d.v, vs.e5);
     }
     if (st == 8) vs.k9 = d.v;
     if (st == 11) vs.k12 = d.v;
   }
-  return FAST && guard_tripped(g);
+}
+
+// The same eleven stages for the tabulated standard step, evaluated incrementally from (v, 1/theta) at the step's start
+// (friction_incr's arithmetic): the steady state of call().  → whether the lane's increments left the series' range
+// (its values are then not to be used).
+// A stage is a serial chain — the last tableau term, rho, the log1p and expm1 series, v, the derivatives, the damping
+// pass: 14 dependent fp64 operations at ~9 cycles each, of which a lone wave fills 4 — and the stages are serial among
+// themselves, so written stage after stage a wave ran at half its issue rate and two waves per SIMD kept the pipe 80 %
+// busy.  What is independent of a stage's evaluation is the NEXT stage's tableau sum over the derivatives already known:
+// here those terms are written between the links of the evaluation's chain (P below), and the sum that waits for the
+// stage is one fma per component.  The compiler keeps the order (near the register limit its scheduler falls back on
+// source order).  Summation order per stage is unchanged: columns ascending.
+// Constants: kStepTable, rows requested two stages ahead of their last-column use (one ahead of the partial sums).
+template <bool DAMP>
+__device__ __forceinline__ bool stages_fast(const Consts &K, const LaneD &L, const double *tab, double h, const double y[3],
+                                            double (&km)[12], double (&kt)[12], const Base &b0, VSums &vs,
+                                            double (&closing)[kClosingLen]) {
+  GuardD g = {0.0f, 0.0f};
+  // the step's eleven loading values in ONE batch of LDS reads, issued before the step's per-step constants are formed
+  // and held in registers from there (early in a step the stage arrays are still empty: there is room) — read one by one
+  // next to their uses each was a separate exposed LDS latency (five s_waitcnt per step)
+  double tv[12];
+#pragma unroll
+  for (int i = 1; i < 12; ++i) tv[i] = tab[i];
+  const ConstRow table = row_of(kStepTable.a[0]);
+  double row[kRowLen], nxt[kRowLen], req[kRowLen];
+#pragma unroll
+  for (int i = 0; i < kRowLen; ++i) {  // the first two rows (three constants) as literals: needed before a load could arrive
+    row[i] = kStepTable0.a[0][i];
+    nxt[i] = kStepTable0.a[1][i];
+  }
+  const FastStep F = fast_step(L, h, y[1], b0);
+  vs.s = RSF_DP_B[0] * vs.k1;
+  vs.e5 = RSF_DP_E5[0] * vs.k1;
+  double psm = 0.0, psth = 0.0;  // stage st's sums over the columns before its last
+  static_for<1, 12>([&](auto st_) {
+    constexpr int st = decltype(st_)::value;
+    constexpr int np = nz_count(st) - 1;  // (the last column, st - 1, is non-zero in every row)
+    static_assert(nz_col(st, np) == st - 1, "stage st's row ends in column st - 1");
+    const double sm = np ? __builtin_fma(row[np], km[st - 1], psm) : row[np] * km[st - 1];
+    const double sth = np ? __builtin_fma(row[np], kt[st - 1], psth) : row[np] * kt[st - 1];
+    if constexpr (st + 2 <= 11) {
+#pragma unroll
+      for (int i = 0; i < row_len(st + 2 <= 11 ? st + 2 : 11); ++i) req[i] = table[kRowLen * (st + 1) + i];
+    } else if constexpr (st == 11) {
+#pragma unroll
+      for (int i = 0; i < kClosingLen; ++i) closing[i] = table[kRowLen * 11 + i];
+    }
+    __builtin_amdgcn_sched_barrier(0);  // (the scheduler would sink the requests to the pin below)
+    // the next stage's sums over the columns known by now, one term per call
+    constexpr int npn = st < 11 ? nz_count(st < 11 ? st + 1 : 11) - 1 : 0;
+    double nsm = 0.0, nsth = 0.0;
+    // P(k, x): term k of those sums, placed beside the chain link that produces x — the empty asm ties x and the two
+    // running sums to one program point, so the link, this term and nothing else of either chain sit between two ties
+    auto P = [&](auto k_, double &link) {
+      constexpr int k = decltype(k_)::value;
+      if constexpr (k < npn) {
+        constexpr int col = nz_col(st < 11 ? st + 1 : 11, k);
+        nsm = k ? __builtin_fma(nxt[k], km[col], nsm) : nxt[k] * km[col];
+        nsth = k ? __builtin_fma(nxt[k], kt[col], nsth) : nxt[k] * kt[col];
+        asm volatile("" : "+v"(link), "+v"(nsm), "+v"(nsth));
+      }
+    };
+    using std::integral_constant;
+    constexpr bool want_v = st >= 5;  // stages 6..12 (1-based) carry weight in the closing sums
+    // friction_incr<DAMP, want_v>(K, L, F, tv[st], b0, sm, sth, g), its chain written out link by link; the links that
+    // have no independent work of their own get the terms
+    const double rho = F.hr * sth;
+    const double tha = F.ha * sm;
+    const double thds = __builtin_fma(F.hd, sth, F.thd0);
+    g.rho = __builtin_fmaxf(g.rho, __builtin_fabsf(hi_as_float(rho)));
+    const double p = __builtin_fma(rho, -0.5, 1.0);
+    const double q = __builtin_fma(rho, rho, -rho);
+    const double pr = p * rho;
+    const double brq = __builtin_fma(F.br0, q, F.br0);
+    double dlt = __builtin_fma(-L.boa, pr, tha);
+    if constexpr (st == 1) asm volatile("" : "+v"(tv[1]), "+v"(dlt));  // the first loading value is not waited for before here
+    const double kvl = L.kprime * tv[st];
+    P(integral_constant<int, 0>{}, dlt);
+    g.dlt = __builtin_fmaxf(g.dlt, __builtin_fabsf(hi_as_float(dlt)));
+    double e = __builtin_fma(1.0 / 120.0, dlt, 1.0 / 24.0);
+    const double bd = b0.v * dlt;
+    e = __builtin_fma(e, dlt, 1.0 / 6.0);
+    P(integral_constant<int, 1>{}, e);
+    e = __builtin_fma(e, dlt, 0.5);
+    P(integral_constant<int, 2>{}, e);
+    e = __builtin_fma(e, dlt, 1.0);
+    P(integral_constant<int, 3>{}, e);
+    double v = __builtin_fma(bd, e, b0.v);
+    P(integral_constant<int, 4>{}, v);
+    Deriv d;
+    d.t = __builtin_fma(-v, thds, 1.0);       // 1 - v theta_s / Dc
+    d.m = __builtin_fma(-L.kprime, v, kvl);    // k' (V_l - v)
+    const double va = v * L.inv_a;
+    double gg = __builtin_fma(-brq, d.t, d.m);  // k'(V_l - v) - (b/theta_s)(1 - v theta_s/Dc)
+    P(integral_constant<int, 5>{}, gg);
+    d.v = va * gg;
+    P(integral_constant<int, 6>{}, d.v);
+    if (DAMP) {
+      d.m = __builtin_fma(-K.k1, d.v, d.m);
+      if (want_v) d.v = va * __builtin_fma(-K.k1, d.v, gg);
+    }
+    P(integral_constant<int, 7>{}, d.m);
+    static_assert(npn <= 8, "P is called eight times");
+    km[st] = d.m;
+    kt[st] = d.t;
+    if constexpr (st + 2 <= 11) pin(req, row_len(st + 2 <= 11 ? st + 2 : 11));
+    else if constexpr (st == 11) pin(closing, kClosingLen);
+    if (want_v) {
+      vs.s = __builtin_fma(row[np + 1], d.v, vs.s);
+      vs.e5 = __builtin_fma(row[np + 2], d.v, vs.e5);
+    }
+    if (st == 8) vs.k9 = d.v;
+    if (st == 11) vs.k12 = d.v;
+#pragma unroll
+    for (int i = 0; i < kRowLen; ++i) { row[i] = nxt[i]; nxt[i] = req[i]; }
+    psm = nsm;
+    psth = nsth;
+  });
+  return guard_tripped(g);
 }
 
 // 8th-order solution k5 and the error estimate of the step; returns err, and err ** (1/8) in fac11.
@@ -247,19 +420,23 @@ __device__ __forceinline__ bool stages(const Consts &K, const LaneD &L, const do
 //           general loop as a step size 1e-7 off — a perturbation of the solution ~1e-7 times a local error.
 template <bool APPROX>
 __device__ __forceinline__ double solution_and_error(double h, const double y[3], const double (&km)[12], const double (&kt)[12],
-                                                     const VSums &vs, double k5[3], double &fac11, double (&s)[3]) {
+                                                     const VSums &vs, const double (&w)[kClosingLen], double k5[3], double &fac11,
+                                                     double (&s)[3]) {
   double e5[3] = {0.0, 0.0, vs.e5}, e3[3];
   s[0] = 0.0; s[1] = 0.0; s[2] = vs.s;
+  // (APPROX = the fast path: constants from kStepTable, loaded during the last stage)
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
-    s[0] += RSF_DP_B[j] * km[RSF_DP_W_STAGE[j]];
-    s[1] += RSF_DP_B[j] * kt[RSF_DP_W_STAGE[j]];
-    e5[0] += RSF_DP_E5[j] * km[RSF_DP_W_STAGE[j]];
-    e5[1] += RSF_DP_E5[j] * kt[RSF_DP_W_STAGE[j]];
+    const double bj = APPROX ? w[2 * j] : RSF_DP_B[j], ej = APPROX ? w[2 * j + 1] : RSF_DP_E5[j];
+    s[0] += bj * km[RSF_DP_W_STAGE[j]];
+    s[1] += bj * kt[RSF_DP_W_STAGE[j]];
+    e5[0] += ej * km[RSF_DP_W_STAGE[j]];
+    e5[1] += ej * kt[RSF_DP_W_STAGE[j]];
   }
-  e3[0] = s[0] - kBhh1 * km[0] - kBhh2 * km[8] - kBhh3 * km[11];
-  e3[1] = s[1] - kBhh1 * kt[0] - kBhh2 * kt[8] - kBhh3 * kt[11];
-  e3[2] = s[2] - kBhh1 * vs.k1 - kBhh2 * vs.k9 - kBhh3 * vs.k12;
+  const double h1 = APPROX ? w[16] : kBhh1, h2 = APPROX ? w[17] : kBhh2, h3 = APPROX ? w[18] : kBhh3;
+  e3[0] = s[0] - h1 * km[0] - h2 * km[8] - h3 * km[11];
+  e3[1] = s[1] - h1 * kt[0] - h2 * kt[8] - h3 * kt[11];
+  e3[2] = s[2] - h1 * vs.k1 - h2 * vs.k9 - h3 * vs.k12;
   double err = 0.0, err2 = 0.0;
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
@@ -307,7 +484,7 @@ __device__ __forceinline__ bool call(const Consts &K, const LaneD &L, const doub
                                      bool resync) {  // resync: wave-uniform
   constexpr double safe = 0.9, facc1 = 1.0 / 0.3, facc2 = 1.0 / 6.0, uround = 2.3e-16;
   const double hmax = fabs(xend - x);
-  double km[12], kt[12], k5[3], ssum[3];
+  double km[12], kt[12], k5[3], ssum[3], closing[kClosingLen];
   VSums vs;
   double h = c.hc;
   bool last = false, reject = false;
@@ -324,8 +501,8 @@ __device__ __forceinline__ bool call(const Consts &K, const LaneD &L, const doub
     const double hs = xend - x;
     double fac11;
     km[0] = k1.m; kt[0] = k1.t; vs.k1 = k1.v;
-    const bool bad = stages<DAMP, true>(K, L, tab, true, x, hs, y, km, kt, b0, vs);
-    const double err = solution_and_error<true>(hs, y, km, kt, vs, k5, fac11, ssum);
+    const bool bad = stages_fast<DAMP>(K, L, tab, hs, y, km, kt, b0, vs, closing);
+    const double err = solution_and_error<true>(hs, y, km, kt, vs, closing, k5, fac11, ssum);
     if (__all(!bad && err <= 1.0)) {
       // first-same-as-last, at xend
       bool full = resync;
@@ -349,9 +526,9 @@ __device__ __forceinline__ bool call(const Consts &K, const LaneD &L, const doub
     const bool standard = last && nstep == 0;  // the tabulated step
     ++nstep;
     km[0] = k1.m; kt[0] = k1.t; vs.k1 = k1.v;
-    stages<DAMP, false>(K, L, tab, standard, x, h, y, km, kt, b0, vs);
+    stages_full<DAMP>(K, L, tab, standard, x, h, y, km, kt, vs);
     double fac11;
-    const double err = solution_and_error<false>(h, y, km, kt, vs, k5, fac11, ssum);
+    const double err = solution_and_error<false>(h, y, km, kt, vs, closing, k5, fac11, ssum);
     double hnew = h * fm::rcp(fmax(facc2, fmin(facc1, fac11 * (1.0 / safe))));
     if (err <= 1.0) {
       k1 = friction<DAMP>(K, L, standard ? tab[11] : loading(K, x + h), k5[0], k5[1], b0);  // first-same-as-last, at x + h: full
@@ -424,13 +601,18 @@ __device__ __forceinline__ double solve(double *lds, const Consts &K, bool resid
     if (!active) continue;
     for (int kk = 0; kk < kn; ++kk) {
       double ak = 0.0;  // after a failed call the reference's arrays keep their zeros (RateStateModel.py:361-381)
+      double obs = WANT_SSQ ? ld[kk] : 0.0;  // read ahead of the call: its LDS latency passes under the step
       if (!failed) {
         failed = !call<DAMP>(K, L, lds + kTab * kk, x, x + delta_t, y, c, (kk & (kResyncDp - 1)) == kResyncDp - 1);
         ak = (y[2] - vprev) * inv_dt;
         vprev = y[2];
       }
       if (WANT_ACC) acc_out[(int64_t)(k0 + kk) * stride] = ak;
-      if (WANT_SSQ) { const double r = ak - ld[kk]; ssq = __builtin_fma(r, r, ssq); }
+      if (WANT_SSQ) {
+        asm volatile("" : "+v"(obs));
+        const double r = ak - obs;
+        ssq = __builtin_fma(r, r, ssq);
+      }
     }
   }
   return ssq;

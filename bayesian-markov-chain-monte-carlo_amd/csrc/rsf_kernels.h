@@ -93,7 +93,9 @@ __device__ __forceinline__ bool lockstep_trip(const double *v, const rsf::Lane (
   for (int t = 0; t <= D; ++t) {
     rsf::Lane Lt = L[t];
     rsf::set_tier<T>(Lt);
+    rsf::tier_enter<T>(st[t], Lt);  // (the TIGHT tier's representation of 1/x, for this trip only)
     bad |= rsf::trip_fast<DAMP, T, NU>(v, Lt, K, st[t], dv[t]);
+    rsf::tier_leave<T>(st[t], Lt);
   }
   return bad;
 }
@@ -185,7 +187,7 @@ __global__ void __launch_bounds__(kMaxBlock) init_kernel(Consts K, InitArgs A) {
 #pragma unroll
           for (int t = 0; t <= D; ++t) {
             st[t] = save[t];
-            rsf::trip_cold<DAMP, NU>(v, L[t], K, st[t], dv[t]);
+            rsf::trip_cold<DAMP, rsf::WIDE, NU>(v, L[t], K, st[t], dv[t]);
           }
         }
         if (tier < rsf::WIDE) ++tier;
@@ -213,7 +215,7 @@ __global__ void __launch_bounds__(kMaxBlock) init_kernel(Consts K, InitArgs A) {
 #pragma unroll
           for (int t = 0; t <= D; ++t) {
             st[t] = save[t];
-            rsf::trip_cold<DAMP, 1>(v, L[t], K, st[t], dv[t]);
+            rsf::trip_cold<DAMP, rsf::WIDE, 1>(v, L[t], K, st[t], dv[t]);
           }
         }
       }

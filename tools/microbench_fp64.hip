@@ -45,6 +45,8 @@ __global__ void __launch_bounds__(256) bench(double *out, unsigned long long *cy
         if (OP == 15) asm volatile("v_mul_f64 %0, %1, %2" : "=v"(r[i]) : "v"(a), "v"(b));
         if (OP == 16) { float f = __builtin_bit_cast(float, __double2hiint(r[i])); asm volatile("v_max3_f32 %0, %0, |%1|, |%1|" : "+v"(gf) : "v"(f)); asm volatile("v_fma_f64 %0, %0, %1, %2" : "+v"(r[i]) : "v"(a), "v"(b)); }  // fma + max3 on its high word: 2 instrs
         if (OP == 17) { asm volatile("v_fma_f64 %0, %0, %1, %2" : "+v"(r[i]) : "v"(a), "v"(b)); asm volatile("v_mul_f64 %0, %1, %1" : "=v"(r2[i]) : "v"(r[i])); }  // fma then a directly dependent mul: 2 instrs
+        if (OP == 18) asm volatile("s_mov_b32 s20, 0x9999999a\n\ts_mov_b32 s21, 0x3fb99999\n\tv_fma_f64 %0, %0, %1, s[20:21]" : "+v"(r[i]) : "v"(a) : "s20", "s21");  // literal pair + fma: 3 instrs, 1 VALU
+        if (OP == 19) asm volatile("s_mov_b32 s20, 0x9999999a\n\tv_fma_f64 %0, %0, %1, %2" : "+v"(r[i]) : "v"(a), "v"(b) : "s20");  // 1 SALU + fma
         if (OP == 11) { int lo = __double2loint(r[i]); asm volatile("v_cndmask_b32 %0, %0, %0, vcc" : "+v"(lo)); r[i] = __hiloint2double(__double2hiint(r[i]), lo); }
       }
     }
@@ -97,6 +99,15 @@ int run(const char *name, int waves_per_simd) {
 }
 
 int main(int argc, char **argv) {
+  if (argc > 1 && argv[1][0] == '2') {  // two waves per SIMD: what dependence and scalar instructions cost the shared pipe (per-SIMD column; 4.0 = pipe full)
+    run<0, 1, 64>("fma dep", 2); run<0, 2, 64>("fma ilp2", 2); run<0, 4, 64>("fma ilp4", 2);
+    run<12, 1, 64>("fma dep sgpr", 2); run<12, 2, 64>("fma ilp2 sgpr", 2);
+    run<19, 1, 64>("smov+fma dep", 2); run<19, 2, 64>("smov+fma ilp2", 2); run<19, 4, 64>("smov+fma ilp4", 2);
+    run<18, 1, 64>("2smov+fma dep", 2); run<18, 2, 64>("2smov+fma ilp2", 2); run<18, 4, 64>("2smov+fma ilp4", 2);
+    run<16, 1, 64>("fma+max3hi dep", 2); run<17, 1, 64>("fma+depmul", 2); run<17, 2, 64>("fma+depmul ilp2", 2);
+    run<0, 1, 64>("fma dep", 1); run<18, 1, 64>("2smov+fma dep", 1); run<19, 1, 64>("smov+fma dep", 1);
+    return 0;
+  }
   if (argc > 1) {  // lone-wave issue cost by instruction form (cycles per wave-instruction; OP 16/17 count 2 per slot)
     run<0, 4, 64>("fma v,v,v,v", 1); run<0, 8, 64>("fma v,v,v,v", 1); run<0, 16, 64>("fma v,v,v,v", 1);
     run<12, 4, 64>("fma v,v,v,s", 1); run<12, 8, 64>("fma v,v,v,s", 1);
