@@ -83,7 +83,7 @@ constexpr int row_len(int st) {  // stage st (0-based, 1..11): its non-zero A en
 
 struct LaneD {
   double inv_dc, kprime, inv_a, b;
-  double boa;  // b/a: the fast path's folded constant (FastStep)
+  double a, boa;  // a and b/a: the fast path's folded constants (FastStep)
 };
 
 // loading velocity V_l(t) = V_ref (1 + exp(-t/20) sin(10 t)), RateStateModel.py:327-329, at a time that is not in the
@@ -148,31 +148,34 @@ struct GuardD {
 // step: the full log/exp is needed only where rounding must not accumulate (kResyncDp).  Outside the range the step's
 // guard trips and the step is taken again by the general loop of call(), every stage evaluated in full.
 //
-// FastStep holds what a step's twelve incremental evaluations share, so that a stage costs ~25 instructions instead of
-// ~30: with sm / sth the stage's tableau sums of the mu / theta derivatives,
-//     rho = (h/theta_0) sth        theta_s/Dc = theta_0/Dc + (h/Dc) sth        dlt = (h/a) sm - (b/a) log1p(rho),
-// and the bracket of dV/dt = (v/a)(dmu/dt - (b/theta) dtheta/dt) is one fma on the two derivatives the stage forms anyway,
-//     g = k'(V_l - v) - (b/theta_s)(1 - v theta_s/Dc),   b/theta_s = (b/theta_0)(1 + q)
-// (rsf_device.h's rhs_fast).  The damping pass (RateStateModel.py:349-353) subtracts the same k1 dV/dt from dmu/dt and from g.
+// FastStep holds what a step's twelve incremental evaluations share.  The fast path carries the stage derivatives SCALED,
+//     km' = (h/a) dmu/dt,   kt' = (h/theta_0) dtheta/dt,   kv' = (h/a) dV/dt,
+// so that the tableau sums ARE the series' arguments — rho = sum_j A kt'_j and (h/a) dmu = sum_j A km'_j, no product per
+// stage — and every other use of a derivative absorbs its factor into a per-step constant:
+//     (h/theta_0) theta_s/Dc = (h/Dc)(1 + rho),      (h/a) k'(V_l - v) = hk (V_l - v),  hk = (h/a) k',
+//     (h/a)(b/theta_s) dtheta/dt = (b/a)(1 + q) kt',  q = rho^2 - rho        (b/theta_s = (b/theta_0)(1 + q)),
+// the bracket of dV/dt = (v/a)(dmu/dt - (b/theta) dtheta/dt) being one fma on the two derivatives the stage forms anyway
+// (rsf_device.h's rhs_fast); the damping pass (RateStateModel.py:349-353) subtracts the same k1 kv' from km' and from the
+// bracket.  The closing sums undo the scaling with a, theta_0, a in place of h (closing_fast).  21 operations per stage.
 struct FastStep {
-  double ha, hd, hr;   // h/a, h/Dc, h/theta_0
-  double thd0, br0;    // theta_0/Dc, b/theta_0
+  double ha, hr, hd, hk;   // h/a, h/theta_0, h/Dc, (h/a) k'
 };
 
-__device__ __forceinline__ FastStep fast_step(const LaneD &L, double h, double theta0, const Base &b0) {
+__device__ __forceinline__ FastStep fast_step(const LaneD &L, double h, const Base &b0) {
   FastStep F;
-  F.ha = h * L.inv_a; F.hd = h * L.inv_dc; F.hr = h * b0.rth;
-  F.thd0 = theta0 * L.inv_dc; F.br0 = L.b * b0.rth;
+  F.ha = h * L.inv_a; F.hr = h * b0.rth; F.hd = h * L.inv_dc;
+  F.hk = F.ha * L.kprime;
   return F;
 }
 
-template <bool DAMP, bool WANT_V>
-__device__ __forceinline__ Deriv friction_incr(const Consts &K, const LaneD &L, const FastStep &F, double vl, const Base &b0, double sm,
-                                               double sth, GuardD &g, Base *at_point = nullptr) {
-  const double rho = F.hr * sth;
+// The UNSCALED derivative at the point (mu, theta) whose series arguments are rho = dtheta/theta_0 and tha = dmu/a
+// (the fast path's closing sums), with (v, 1/theta) there: the step's end point, first stage of the next step.
+template <bool DAMP>
+__device__ __forceinline__ Deriv friction_incr(const Consts &K, const LaneD &L, double theta0, double vl, const Base &b0, double tha,
+                                               double rho, GuardD &g, Base &at_point) {
   g.rho = __builtin_fmaxf(g.rho, __builtin_fabsf(hi_as_float(rho)));
   const double p = __builtin_fma(rho, -0.5, 1.0);
-  const double dlt = __builtin_fma(-L.boa, p * rho, F.ha * sm);
+  const double dlt = __builtin_fma(-L.boa, p * rho, tha);
   g.dlt = __builtin_fmaxf(g.dlt, __builtin_fabsf(hi_as_float(dlt)));
   double e = 1.0 / 120.0;
   e = __builtin_fma(e, dlt, 1.0 / 24.0);
@@ -181,17 +184,18 @@ __device__ __forceinline__ Deriv friction_incr(const Consts &K, const LaneD &L, 
   e = __builtin_fma(e, dlt, 1.0);
   const double v = __builtin_fma(b0.v * dlt, e, b0.v);
   const double q = __builtin_fma(rho, rho, -rho);
-  if (at_point) { at_point->v = v; at_point->rth = __builtin_fma(b0.rth, q, b0.rth); }
-  const double kvl = L.kprime * vl;
+  at_point.v = v;
+  at_point.rth = __builtin_fma(b0.rth, q, b0.rth);
+  const double thd0 = theta0 * L.inv_dc;
   Deriv d;
-  d.t = __builtin_fma(-v, __builtin_fma(F.hd, sth, F.thd0), 1.0);       // 1 - v theta_s / Dc
-  d.m = __builtin_fma(-L.kprime, v, kvl);                                // k' (V_l - v)
-  double gg = __builtin_fma(-__builtin_fma(F.br0, q, F.br0), d.t, d.m);    // k'(V_l - v) - (b/theta_s)(1 - v theta_s/Dc)
+  d.t = __builtin_fma(-v, __builtin_fma(thd0, rho, thd0), 1.0);   // 1 - v theta_s / Dc,  theta_s = theta_0 (1 + rho)
+  d.m = L.kprime * (vl - v);                                       // k' (V_l - v)
+  const double gg = __builtin_fma(-L.b * at_point.rth, d.t, d.m);  // k'(V_l - v) - (b/theta_s)(1 - v theta_s/Dc)
   const double va = v * L.inv_a;
   d.v = va * gg;
   if (DAMP) {
     d.m = __builtin_fma(-K.k1, d.v, d.m);
-    if (WANT_V) d.v = va * __builtin_fma(-K.k1, d.v, gg);
+    d.v = va * __builtin_fma(-K.k1, d.v, gg);
   }
   return d;
 }
@@ -316,7 +320,10 @@ __device__ __forceinline__ bool stages_fast(const Consts &K, const LaneD &L, con
     row[i] = kStepTable0.a[0][i];
     nxt[i] = kStepTable0.a[1][i];
   }
-  const FastStep F = fast_step(L, h, y[1], b0);
+  const FastStep F = fast_step(L, h, b0);
+  km[0] *= F.ha;  // the first stage's derivative arrives unscaled (Carry)
+  kt[0] *= F.hr;
+  vs.k1 *= F.ha;
   vs.s = RSF_DP_B[0] * vs.k1;
   vs.e5 = RSF_DP_E5[0] * vs.k1;
   double psm = 0.0, psth = 0.0;  // stage st's sums over the columns before its last
@@ -350,19 +357,17 @@ __device__ __forceinline__ bool stages_fast(const Consts &K, const LaneD &L, con
     };
     using std::integral_constant;
     constexpr bool want_v = st >= 5;  // stages 6..12 (1-based) carry weight in the closing sums
-    // friction_incr<DAMP, want_v>(K, L, F, tv[st], b0, sm, sth, g), its chain written out link by link; the links that
-    // have no independent work of their own get the terms
-    const double rho = F.hr * sth;
-    const double tha = F.ha * sm;
-    const double thds = __builtin_fma(F.hd, sth, F.thd0);
+    // the stage's evaluation (FastStep), its chain written out link by link; the links that have no independent work
+    // of their own get the terms
+    const double rho = sth;
     g.rho = __builtin_fmaxf(g.rho, __builtin_fabsf(hi_as_float(rho)));
+    const double thds = __builtin_fma(F.hd, rho, F.hd);
     const double p = __builtin_fma(rho, -0.5, 1.0);
     const double q = __builtin_fma(rho, rho, -rho);
     const double pr = p * rho;
-    const double brq = __builtin_fma(F.br0, q, F.br0);
-    double dlt = __builtin_fma(-L.boa, pr, tha);
-    if constexpr (st == 1) asm volatile("" : "+v"(tv[1]), "+v"(dlt));  // the first loading value is not waited for before here
-    const double kvl = L.kprime * tv[st];
+    const double bq = __builtin_fma(L.boa, q, L.boa);
+    double dlt = __builtin_fma(-L.boa, pr, sm);
+    const double kvl = F.hk * tv[st];
     P(integral_constant<int, 0>{}, dlt);
     g.dlt = __builtin_fmaxf(g.dlt, __builtin_fabsf(hi_as_float(dlt)));
     double e = __builtin_fma(1.0 / 120.0, dlt, 1.0 / 24.0);
@@ -376,10 +381,10 @@ __device__ __forceinline__ bool stages_fast(const Consts &K, const LaneD &L, con
     double v = __builtin_fma(bd, e, b0.v);
     P(integral_constant<int, 4>{}, v);
     Deriv d;
-    d.t = __builtin_fma(-v, thds, 1.0);       // 1 - v theta_s / Dc
-    d.m = __builtin_fma(-L.kprime, v, kvl);    // k' (V_l - v)
+    d.t = __builtin_fma(-v, thds, F.hr);   // (h/theta_0)(1 - v theta_s / Dc)
+    d.m = __builtin_fma(-F.hk, v, kvl);    // (h/a) k' (V_l - v)
     const double va = v * L.inv_a;
-    double gg = __builtin_fma(-brq, d.t, d.m);  // k'(V_l - v) - (b/theta_s)(1 - v theta_s/Dc)
+    double gg = __builtin_fma(-bq, d.t, d.m);  // (h/a)(k'(V_l - v) - (b/theta_s)(1 - v theta_s/Dc))
     P(integral_constant<int, 5>{}, gg);
     d.v = va * gg;
     P(integral_constant<int, 6>{}, d.v);
@@ -407,54 +412,78 @@ __device__ __forceinline__ bool stages_fast(const Consts &K, const LaneD &L, con
   return guard_tripped(g);
 }
 
-// 8th-order solution k5 and the error estimate of the step; returns err, and err ** (1/8) in fac11.
-// The solution is formed as the reference forms it.  The error norm and the step-size factor steer h and the accept test
-// err <= 1:
-//   !APPROX (general loop): reciprocals, square root and err ** (1/8) to ~1 ulp (rsf_math.h) — where the controller
-//           really chooses step sizes (HINIT's first interval, stiff small-Dc lanes: thousands of steps whose sizes
-//           feed back into the solution at the level of the tolerance), the step sequence has to be the reference's;
-//   APPROX  (fast path): the step IS the output interval whatever the controller says, and the carried prediction is
-//           only compared with it (x + 1.01 h > xend), so the hardware's approximate reciprocal / reciprocal square root /
-//           square root (v_rcp_f64, v_rsq_f64, v_sqrt_f64: ~1e-7 relative, one instruction each) stand in for dop853.f's
-//           divisions, sqrt and pow: err ** (1/8) is three square roots.  A prediction that ends the steady state enters the
-//           general loop as a step size 1e-7 off — a perturbation of the solution ~1e-7 times a local error.
-template <bool APPROX>
+// 8th-order solution k5 and the error estimate of a step of the general loop; returns err, and err ** (1/8) in fac11.
+// The solution is formed as the reference forms it; reciprocals, square root and err ** (1/8) to ~1 ulp (rsf_math.h):
+// where the controller really chooses step sizes (HINIT's first interval, stiff small-Dc lanes: thousands of steps whose
+// sizes feed back into the solution at the level of the tolerance), the step sequence has to be the reference's.
 __device__ __forceinline__ double solution_and_error(double h, const double y[3], const double (&km)[12], const double (&kt)[12],
-                                                     const VSums &vs, const double (&w)[kClosingLen], double k5[3], double &fac11,
-                                                     double (&s)[3]) {
-  double e5[3] = {0.0, 0.0, vs.e5}, e3[3];
-  s[0] = 0.0; s[1] = 0.0; s[2] = vs.s;
-  // (APPROX = the fast path: constants from kStepTable, loaded during the last stage)
+                                                     const VSums &vs, double k5[3], double &fac11) {
+  double e5[3] = {0.0, 0.0, vs.e5}, e3[3], s[3] = {0.0, 0.0, vs.s};
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
-    const double bj = APPROX ? w[2 * j] : RSF_DP_B[j], ej = APPROX ? w[2 * j + 1] : RSF_DP_E5[j];
-    s[0] += bj * km[RSF_DP_W_STAGE[j]];
-    s[1] += bj * kt[RSF_DP_W_STAGE[j]];
-    e5[0] += ej * km[RSF_DP_W_STAGE[j]];
-    e5[1] += ej * kt[RSF_DP_W_STAGE[j]];
+    s[0] += RSF_DP_B[j] * km[RSF_DP_W_STAGE[j]];
+    s[1] += RSF_DP_B[j] * kt[RSF_DP_W_STAGE[j]];
+    e5[0] += RSF_DP_E5[j] * km[RSF_DP_W_STAGE[j]];
+    e5[1] += RSF_DP_E5[j] * kt[RSF_DP_W_STAGE[j]];
   }
-  const double h1 = APPROX ? w[16] : kBhh1, h2 = APPROX ? w[17] : kBhh2, h3 = APPROX ? w[18] : kBhh3;
-  e3[0] = s[0] - h1 * km[0] - h2 * km[8] - h3 * km[11];
-  e3[1] = s[1] - h1 * kt[0] - h2 * kt[8] - h3 * kt[11];
-  e3[2] = s[2] - h1 * vs.k1 - h2 * vs.k9 - h3 * vs.k12;
+  e3[0] = s[0] - kBhh1 * km[0] - kBhh2 * km[8] - kBhh3 * km[11];
+  e3[1] = s[1] - kBhh1 * kt[0] - kBhh2 * kt[8] - kBhh3 * kt[11];
+  e3[2] = s[2] - kBhh1 * vs.k1 - kBhh2 * vs.k9 - kBhh3 * vs.k12;
   double err = 0.0, err2 = 0.0;
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
     k5[i] = y[i] + h * s[i];
     const double sk = kAtol + kRtol * fmax(fabs(y[i]), fabs(k5[i]));
-    const double isk = APPROX ? __builtin_amdgcn_rcp(sk) : fm::rcp(sk);
+    const double isk = fm::rcp(sk);
     err2 += (e3[i] * isk) * (e3[i] * isk);
     err += (e5[i] * isk) * (e5[i] * isk);
   }
   double deno = err + 0.01 * err2;
   if (deno <= 0.0) deno = 1.0;
-  if (APPROX) {
-    err = fabs(h) * err * __builtin_amdgcn_rsq(3.0 * deno);
-    fac11 = __builtin_amdgcn_sqrt(__builtin_amdgcn_sqrt(__builtin_amdgcn_sqrt(err)));  // 0 stays 0, NaN stays NaN
-  } else {
-    err = fabs(h) * err * sqrt(fm::rcp(3.0 * deno));
-    fac11 = err > 0.0 ? fm::exp(0.125 * fm::log(err)) : (err == 0.0 ? 0.0 : err);  // err ** (1/8); NaN stays NaN
+  err = fabs(h) * err * sqrt(fm::rcp(3.0 * deno));
+  fac11 = err > 0.0 ? fm::exp(0.125 * fm::log(err)) : (err == 0.0 ? 0.0 : err);  // err ** (1/8); NaN stays NaN
+  return err;
+}
+
+// The same for the fast path, from the SCALED stage derivatives (FastStep): the sums s carry the factors h/a, h/theta_0,
+// h/a, so h s_i is a s_0, theta_0 s_1, a s_2, and with w_i = {a, theta_0, a} / sk_i the norm's |h| cancels:
+//     err = |h| sqrt(sum (e5_i/sk_i)^2 / 3) * [sum (e5/sk)^2 / (sum (e5/sk)^2 + 0.01 sum (e3/sk)^2)]^(1/2)   (dop853.f)
+//         = E5 / sqrt(3 (E5 + 0.01 E3)),   E5 = sum (e5'_i w_i)^2,  E3 = sum (e3'_i w_i)^2.
+// Here the step IS the output interval whatever the controller says, and the carried prediction is only compared with it
+// (x + 1.01 h > xend), so the hardware's approximate reciprocal / reciprocal square root / square root (v_rcp_f64,
+// v_rsq_f64, v_sqrt_f64: ~1e-7 relative, one instruction each) stand in for dop853.f's divisions, sqrt and pow:
+// err ** (1/8) is three square roots.  A prediction that ends the steady state enters the general loop as a step size
+// 1e-7 off — a perturbation of the solution ~1e-7 times a local error.  Constants: the closing row of kStepTable, loaded
+// during the last stage.  s[0], s[1] are left for the end point's evaluation (they are its series arguments).
+__device__ __forceinline__ double closing_fast(const LaneD &L, const double y[3], const double (&km)[12], const double (&kt)[12],
+                                               const VSums &vs, const double (&w)[kClosingLen], double k5[3], double &fac11,
+                                               double (&s)[3]) {
+  double e5[3] = {0.0, 0.0, vs.e5}, e3[3];
+  s[0] = 0.0; s[1] = 0.0; s[2] = vs.s;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    s[0] += w[2 * j] * km[RSF_DP_W_STAGE[j]];
+    s[1] += w[2 * j] * kt[RSF_DP_W_STAGE[j]];
+    e5[0] += w[2 * j + 1] * km[RSF_DP_W_STAGE[j]];
+    e5[1] += w[2 * j + 1] * kt[RSF_DP_W_STAGE[j]];
   }
+  e3[0] = s[0] - w[16] * km[0] - w[17] * km[8] - w[18] * km[11];
+  e3[1] = s[1] - w[16] * kt[0] - w[17] * kt[8] - w[18] * kt[11];
+  e3[2] = s[2] - w[16] * vs.k1 - w[17] * vs.k9 - w[18] * vs.k12;
+  const double unscale[3] = {L.a, y[1], L.a};
+  double err = 0.0, err2 = 0.0;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    k5[i] = __builtin_fma(unscale[i], s[i], y[i]);
+    const double sk = kAtol + kRtol * fmax(fabs(y[i]), fabs(k5[i]));
+    const double wi = unscale[i] * __builtin_amdgcn_rcp(sk);
+    err2 += (e3[i] * wi) * (e3[i] * wi);
+    err += (e5[i] * wi) * (e5[i] * wi);
+  }
+  double deno = err + 0.01 * err2;
+  if (deno <= 0.0) deno = 1.0;
+  err = err * __builtin_amdgcn_rsq(3.0 * deno);
+  fac11 = __builtin_amdgcn_sqrt(__builtin_amdgcn_sqrt(__builtin_amdgcn_sqrt(err)));  // 0 stays 0, NaN stays NaN
   return err;
 }
 
@@ -502,20 +531,20 @@ __device__ __forceinline__ bool call(const Consts &K, const LaneD &L, const doub
     double fac11;
     km[0] = k1.m; kt[0] = k1.t; vs.k1 = k1.v;
     const bool bad = stages_fast<DAMP>(K, L, tab, hs, y, km, kt, b0, vs, closing);
-    const double err = solution_and_error<true>(hs, y, km, kt, vs, closing, k5, fac11, ssum);
+    const double err = closing_fast(L, y, km, kt, vs, closing, k5, fac11, ssum);
     if (__all(!bad && err <= 1.0)) {
       // first-same-as-last, at xend
       bool full = resync;
       if (!full) {
         GuardD g = {0.0f, 0.0f};
-        c.kf = friction_incr<DAMP, true>(K, L, fast_step(L, hs, y[1], b0), tab[11], b0, ssum[0], ssum[1], g, &c.bf);
+        c.kf = friction_incr<DAMP>(K, L, y[1], tab[11], b0, ssum[0], ssum[1], g, c.bf);
         full = __any(guard_tripped(g));
       }
       if (full) c.kf = friction<DAMP>(K, L, tab[11], k5[0], k5[1], c.bf);
 #pragma unroll
       for (int i = 0; i < 3; ++i) y[i] = k5[i];
       x = x + hs;
-      c.hc = hs * fm::rcp(fmax(facc2, fmin(facc1, fac11 * (1.0 / safe))));
+      c.hc = hs * __builtin_amdgcn_rcp(fmax(facc2, fmin(facc1, fac11 * (1.0 / safe))));  // (a prediction: closing_fast)
       return true;
     }
   }
@@ -528,7 +557,7 @@ __device__ __forceinline__ bool call(const Consts &K, const LaneD &L, const doub
     km[0] = k1.m; kt[0] = k1.t; vs.k1 = k1.v;
     stages_full<DAMP>(K, L, tab, standard, x, h, y, km, kt, vs);
     double fac11;
-    const double err = solution_and_error<false>(h, y, km, kt, vs, closing, k5, fac11, ssum);
+    const double err = solution_and_error(h, y, km, kt, vs, k5, fac11);
     double hnew = h * fm::rcp(fmax(facc2, fmin(facc1, fac11 * (1.0 / safe))));
     if (err <= 1.0) {
       k1 = friction<DAMP>(K, L, standard ? tab[11] : loading(K, x + h), k5[0], k5[1], b0);  // first-same-as-last, at x + h: full
@@ -571,6 +600,7 @@ __device__ __forceinline__ void stage_chunk_dp(double *lds, const Consts &K, int
 __device__ __forceinline__ LaneD make_lane_dp(double dc, double a, double b) {
   LaneD L;
   L.inv_dc = 1.0 / dc; L.kprime = (1e-2 * 10) / dc; L.inv_a = 1.0 / a; L.b = b;
+  L.a = a;
   L.boa = b * L.inv_a;
   return L;
 }
