@@ -62,6 +62,7 @@ struct Lane {
   double cv;      // cacc vk       : acceleration sample = cv * (g-weighted RK4 sum of the step)
   double h6v;     // (h/6) vk      : velocity increment of a step = h6v * that sum
   double boa;     // b/a
+  double nhboa;   // -b/2a : (b/a) log1p(rho) = rho (b/a - (b/2a) rho) in the TIGHT tier, two fmas with dlt
   double tc;      // -mu_ref/a
   double hhd, hd, h6d;  // (h/2)/Dc, h/Dc, (h/6)/Dc : theta increments in x units
   double inv_hhd, bh;   // 1/hhd and beta/hhd: the TIGHT tier carries hhd/x in place of 1/x (rk4_fast)
@@ -95,6 +96,7 @@ __device__ __forceinline__ Lane make_lane(double dc, double a, double b, const C
   L.hhd = K.hh * L.vdc;
   L.hd = K.h * L.vdc;
   L.h6d = K.h6 * L.vdc;
+  L.nhboa = -0.5 * L.boa;
   L.inv_hhd = fm::rcp(L.hhd);
   L.bh = L.beta * L.inv_hhd;
   set_tier<2>(L);
@@ -109,9 +111,8 @@ __device__ __forceinline__ Lane make_lane(double dc, double a, double b, const C
 
 // Integration state of one lane: ms = mu/k', x = V_ref theta/Dc, V, and the transcendental parts of the RHS at
 // that point:  w = v/V_ref = exp(mu/a - mu_ref/a - (b/a) log x),   rx = 1/x.
-// INSIDE the TIGHT tier's loops rx holds hhd/x instead (tier_enter / tier_leave): what a step needs of 1/x are the three
-// multiples (h/2Dc)/x, (h/6Dc)/x and beta/x, and the step-end update 1/x' = (1/x)(1 + q) is indifferent to a constant
-// factor — carrying the first multiple makes it free and the other two one product each (-1 instruction per step).
+// INSIDE the TIGHT tier's loops rx holds Rh = hhd/x instead (tier_enter / tier_leave): the step-end update
+// 1/x' = (1/x)(1 + q) is indifferent to a constant factor, and the tier's step works on theta derivatives scaled by Rh (rk4_tight).
 struct State {
   double ms, x, V;
   double w, rx;
@@ -189,14 +190,6 @@ __device__ __forceinline__ void eval_full_t(State &s, const Lane &L, const Const
 // result and the loop branch: +3 % at cfg1.)
 enum Tier : int { TIGHT = 0, NARROW = 1, WIDE = 2 };
 
-// beta/x of a stage.  TIGHT stages never form 1/x at the stage point: with 1/x' = (1/x)(1 + q), q = rho^2 - rho (eval_incr
-// hands q back in place of 1/x'), beta/x' = br0 + br0 q where br0 = beta/x at the step's start.
-template <int T>
-__device__ __forceinline__ double stage_brx(double rx_or_q, double br0, const Lane &L) {
-  if (T == TIGHT) return __builtin_fma(br0, rx_or_q, br0);
-  return L.beta * rx_or_q;
-}
-
 struct Guard {
   float rho, dlt;
   float dlt_h;  // TIGHT: |dlt| of the two half-step stages, held to 2^-10 (truncation of their expm1 series < 8e-18)
@@ -215,42 +208,30 @@ __device__ __forceinline__ void set_tier(Lane &L) {
   asm volatile("" : "+v"(L.c_l1p), "+v"(L.c_em1), "+v"(L.c_em1h));  // opaque: stays a register value, not re-materialised per step
 }
 
-template <int T, bool STAGE, bool HALF = false>
+// the NARROW / WIDE form (the TIGHT tier has its own, tight_incr)
+template <int T>
 __device__ __forceinline__ void eval_incr(double kf, double dms_dt, double R, double dth_dt, double x1, const Lane &L, double w0,
-                                          double rx0, double &w, double &rx, Guard &g) {  // TIGHT && STAGE: rx returns q (stage_brx)
+                                          double rx0, double &w, double &rx, Guard &g) {
+  static_assert(T == NARROW || T == WIDE, "");
   // dk = kf * dms_dt (kf: kia times the step fraction);  rho = R * dth_dt (R: step fraction / Dc / x, once per step)
   const double rho = dth_dt * R;
   g.rho = __builtin_fmaxf(g.rho, __builtin_fabsf(hi_as_float(rho)));
   double p;
-  if (T == TIGHT) {
-    p = __builtin_fma(rho, -0.5, 1.0);
+  if (T == WIDE) {
+    p = fm::hfma(L.c_l1p, rho, -1.0 / 6.0);
+    p = fm::hfma(p, rho, 1.0 / 5.0);
   } else {
-    if (T == WIDE) {
-      p = fm::hfma(L.c_l1p, rho, -1.0 / 6.0);
-      p = fm::hfma(p, rho, 1.0 / 5.0);
-    } else {
-      p = fm::hfma(L.c_l1p, rho, 1.0 / 5.0);
-    }
-    p = fm::hfma(p, rho, -1.0 / 4.0);
-    p = fm::hfma(p, rho, 1.0 / 3.0);
-    p = __builtin_fma(p, rho, -0.5);
-    p = __builtin_fma(p, rho, 1.0);
+    p = fm::hfma(L.c_l1p, rho, 1.0 / 5.0);
   }
+  p = fm::hfma(p, rho, -1.0 / 4.0);
+  p = fm::hfma(p, rho, 1.0 / 3.0);
+  p = __builtin_fma(p, rho, -0.5);
+  p = __builtin_fma(p, rho, 1.0);
   const double dlt = __builtin_fma(-(L.boa * rho), p, kf * dms_dt);  // d1 -> rho -> p -> dlt: three deep
-  // TIGHT: expm1 to dlt^4/24 at every stage.  Half-step stages are held to |dlt| < 2^-10 (truncation dlt^5/120 < 7.4e-18 relative);
-  // the full-step stage and the step's end point to |dlt| < 2^-9, where the same series truncates at < 2^-45/120 = 2.4e-16 —
-  // one ulp at the guard's edge, 8e-18 at the |dlt| ~ 1e-3 of Dc ~ 1000 — which saves their sixth-degree term.
-  constexpr bool kShort = T == TIGHT && HALF;  // guard accumulator of the half-step stages (2^-10)
-  if (kShort) g.dlt_h = __builtin_fmaxf(g.dlt_h, __builtin_fabsf(hi_as_float(dlt)));
-  else g.dlt = __builtin_fmaxf(g.dlt, __builtin_fabsf(hi_as_float(dlt)));
-  double e;
-  if (T == TIGHT) {
-    e = L.c_em1h;
-  } else {
-    e = fm::hfma(L.c_em1, dlt, 1.0 / 720.0);
-    e = fm::hfma(e, dlt, 1.0 / 120.0);
-    e = fm::hfma(e, dlt, 1.0 / 24.0);
-  }
+  g.dlt = __builtin_fmaxf(g.dlt, __builtin_fabsf(hi_as_float(dlt)));
+  double e = fm::hfma(L.c_em1, dlt, 1.0 / 720.0);
+  e = fm::hfma(e, dlt, 1.0 / 120.0);
+  e = fm::hfma(e, dlt, 1.0 / 24.0);
   e = fm::hfma(e, dlt, 1.0 / 6.0);
   e = __builtin_fma(e, dlt, 0.5);
   e = __builtin_fma(e, dlt, 1.0);
@@ -259,12 +240,9 @@ __device__ __forceinline__ void eval_incr(double kf, double dms_dt, double R, do
     rx = __builtin_fma(-rho, rx0, rx0);
     rx = __builtin_fma(rx, __builtin_fma(-x1, rx, 1.0), rx);
     rx = __builtin_fma(rx, __builtin_fma(-x1, rx, 1.0), rx);
-  } else if (T == NARROW) {
+  } else {
     rx = __builtin_fma(rx0, __builtin_fma(rho, rho, -rho), rx0);
     rx = __builtin_fma(rx, __builtin_fma(-x1, rx, 1.0), rx);
-  } else {
-    const double q = __builtin_fma(rho, rho, -rho);
-    rx = STAGE ? q : __builtin_fma(rx0, q, rx0);  // exact to rounding for |rho| < 2^-20; like w, resynced
   }
 }
 
@@ -315,36 +293,105 @@ __device__ __forceinline__ double rk4_cold(State &s, double vl0, double vlm, dou
   return s2;
 }
 
+// The TIGHT tier's step.  s.rx holds Rh = (h/2Dc)/x (tier_enter), and every theta derivative of the step is carried
+// SCALED by it, d1' = Rh (1 - w x): then rho of a half-step stage IS the previous stage's d1' (of the full-step stage
+// twice it, of the step's end a third of the weighted sum), and with Rh x_0 = h/2Dc =: hhd the scaled derivative needs
+// only constants and the previous d1':
+//     Rh x_s = hhd + c_s d1'_prev  (c_s = hhd, hhd, hd),      d1' = Rh - w (Rh x_s),      (beta/x_s) d1 = bh (1 + q) d1',  bh = beta/hhd,
+// so neither rho = R d1 (four products per step) nor Rf, R6 and beta/x_0 (three per step) are formed: 5 instructions
+// fewer than the unscaled form.  x itself is updated once, x' = x (1 + rho_end).  Rounding: Rh is carried by products
+// (resynced every kResync steps), so Rh x_0 = hhd holds to ~1e-15 relative, an ABSOLUTE perturbation of that size on
+// d1 = 1 - w x — 1e-12 of the dtheta/dt ~ 1e-3 of a Dc ~ 1000 lane, inside the Tier-1 figures of DESIGN §4.
+template <bool HALF>
+__device__ __forceinline__ void tight_incr(double rho, double dk, const Lane &L, double w0, double &w, double &q, Guard &g) {
+  g.rho = __builtin_fmaxf(g.rho, __builtin_fabsf(hi_as_float(rho)));
+  const double dlt = __builtin_fma(-rho, __builtin_fma(rho, L.nhboa, L.boa), dk);  // dk - (b/a)(rho - rho^2/2)
+  // expm1 to dlt^4/24 at every stage: half-step stages are held to |dlt| < 2^-10, the others to 2^-9
+  if (HALF) g.dlt_h = __builtin_fmaxf(g.dlt_h, __builtin_fabsf(hi_as_float(dlt)));
+  else g.dlt = __builtin_fmaxf(g.dlt, __builtin_fabsf(hi_as_float(dlt)));
+  double e = fm::hfma(L.c_em1h, dlt, 1.0 / 6.0);
+  e = __builtin_fma(e, dlt, 0.5);
+  e = __builtin_fma(e, dlt, 1.0);
+  w = __builtin_fma(w0 * dlt, e, w0);
+  q = __builtin_fma(rho, rho, -rho);  // 1/x' = (1/x)(1 + q)
+}
+
+// d0 = V_l - V_ref w,  d1' = Rh - w xr  (xr = Rh x at the stage),  g = d0 - brx d1'  (brx = bh (1 + q)) and the damping pass
+template <bool DAMP>
+__device__ __forceinline__ void rhs_tight(double w, double xr, double Rh, double vl, double brx, const Lane &L, const Consts &K,
+                                          double &d0, double &d1, double &g) {
+  d1 = __builtin_fma(-w, xr, Rh);
+  d0 = __builtin_fma(-K.V_ref, w, vl);
+  g = __builtin_fma(-brx, d1, d0);
+  if (DAMP) {
+    const double kw = L.kvk * w;
+    d0 = __builtin_fma(-kw, g, d0);
+    g = __builtin_fma(-kw, g, g);
+  }
+}
+
+template <bool DAMP>
+__device__ __forceinline__ double rk4_tight(State &s, double vl0, double vlm, double vl1, const Lane &L, const Consts &K, Guard &g) {
+  double a0, a1, a2, b0, b1, b2, c0, c1, c2, e0, e1, e2, w, q;
+  const double Rh = s.rx;
+  rhs_tight<DAMP>(s.w, L.hhd, Rh, vl0, L.bh, L, K, a0, a1, a2);
+  double sv = s.w * a2;  // k1 + k4 of dV/dt (in units of vk), and k2 + k3 below: 5 instructions for the weighted sum
+  tight_incr<true>(a1, L.khh * a0, L, s.w, w, q, g);
+  rhs_tight<DAMP>(w, __builtin_fma(L.hhd, a1, L.hhd), Rh, vlm, __builtin_fma(L.bh, q, L.bh), L, K, b0, b1, b2);
+  double sm = w * b2;
+  tight_incr<true>(b1, L.khh * b0, L, s.w, w, q, g);
+  rhs_tight<DAMP>(w, __builtin_fma(L.hhd, b1, L.hhd), Rh, vlm, __builtin_fma(L.bh, q, L.bh), L, K, c0, c1, c2);
+  sm = __builtin_fma(w, c2, sm);
+  tight_incr<false>(c1 + c1, L.kh * c0, L, s.w, w, q, g);
+  rhs_tight<DAMP>(w, __builtin_fma(L.hd, c1, L.hhd), Rh, vl1, __builtin_fma(L.bh, q, L.bh), L, K, e0, e1, e2);
+  sv = __builtin_fma(w, e2, sv);
+  const double t0 = a0 + 2.0 * b0 + 2.0 * c0 + e0;
+  const double t1 = a1 + 2.0 * b1 + 2.0 * c1 + e1;
+  const double rho = t1 * (1.0 / 3.0);  // (h/6Dc)/x times the unscaled sum
+  tight_incr<false>(rho, L.kh6 * t0, L, s.w, w, q, g);
+  s.ms = __builtin_fma(K.h6, t0, s.ms);
+  s.x = __builtin_fma(s.x, rho, s.x);
+  s.w = w;
+  s.rx = __builtin_fma(Rh, q, Rh);  // exact to rounding for |rho| < 2^-20; like w, resynced
+  return __builtin_fma(2.0, sm, sv);
+}
+
 template <bool DAMP, int T>
-__device__ __forceinline__ double rk4_fast(State &s, double vl0, double vlm, double vl1, const Lane &L,
-                                           const Consts &K, Guard &g) {
+__device__ __forceinline__ double rk4_wider(State &s, double vl0, double vlm, double vl1, const Lane &L,
+                                            const Consts &K, Guard &g) {
   double a0, a1, a2, b0, b1, b2, c0, c1, c2, e0, e1, e2, w, rx, xs;
-  // rho of a stage = its theta derivative times Rh / Rf / R6;  br0 = beta/x at the step's start  (TIGHT: s.rx is hhd/x)
-  const double Rh = T == TIGHT ? s.rx : L.hhd * s.rx, Rf = Rh + Rh, R6 = T == TIGHT ? s.rx * (1.0 / 3.0) : L.h6d * s.rx;
-  const double br0 = T == TIGHT ? L.bh * s.rx : L.beta * s.rx;
-  rhs_fast<DAMP>(s.w, s.x, vl0, br0, L, K, a0, a1, a2);
+  // rho of a stage = its theta derivative times Rh / Rf / R6
+  const double Rh = L.hhd * s.rx, Rf = Rh + Rh, R6 = L.h6d * s.rx;
+  rhs_fast<DAMP>(s.w, s.x, vl0, L.beta * s.rx, L, K, a0, a1, a2);
   double sv = s.w * a2;  // k1 + k4 of dV/dt (in units of vk), and k2 + k3 below: 5 instructions for the weighted sum
   xs = __builtin_fma(L.hhd, a1, s.x);
-  eval_incr<T, true, true>(L.khh, a0, Rh, a1, xs, L, s.w, s.rx, w, rx, g);
-  rhs_fast<DAMP>(w, xs, vlm, stage_brx<T>(rx, br0, L), L, K, b0, b1, b2);
+  eval_incr<T>(L.khh, a0, Rh, a1, xs, L, s.w, s.rx, w, rx, g);
+  rhs_fast<DAMP>(w, xs, vlm, L.beta * rx, L, K, b0, b1, b2);
   double sm = w * b2;
   xs = __builtin_fma(L.hhd, b1, s.x);
-  eval_incr<T, true, true>(L.khh, b0, Rh, b1, xs, L, s.w, s.rx, w, rx, g);
-  rhs_fast<DAMP>(w, xs, vlm, stage_brx<T>(rx, br0, L), L, K, c0, c1, c2);
+  eval_incr<T>(L.khh, b0, Rh, b1, xs, L, s.w, s.rx, w, rx, g);
+  rhs_fast<DAMP>(w, xs, vlm, L.beta * rx, L, K, c0, c1, c2);
   sm = __builtin_fma(w, c2, sm);
   xs = __builtin_fma(L.hd, c1, s.x);
-  eval_incr<T, true>(L.kh, c0, Rf, c1, xs, L, s.w, s.rx, w, rx, g);
-  rhs_fast<DAMP>(w, xs, vl1, stage_brx<T>(rx, br0, L), L, K, e0, e1, e2);
+  eval_incr<T>(L.kh, c0, Rf, c1, xs, L, s.w, s.rx, w, rx, g);
+  rhs_fast<DAMP>(w, xs, vl1, L.beta * rx, L, K, e0, e1, e2);
   sv = __builtin_fma(w, e2, sv);
   const double t0 = a0 + 2.0 * b0 + 2.0 * c0 + e0;
   const double t1 = a1 + 2.0 * b1 + 2.0 * c1 + e1;
   const double x1 = __builtin_fma(L.h6d, t1, s.x);
-  eval_incr<T, false>(L.kh6, t0, R6, t1, x1, L, s.w, s.rx, w, rx, g);
+  eval_incr<T>(L.kh6, t0, R6, t1, x1, L, s.w, s.rx, w, rx, g);
   s.ms = __builtin_fma(K.h6, t0, s.ms);
   s.x = x1;
   s.w = w;
   s.rx = rx;
   return __builtin_fma(2.0, sm, sv);
+}
+
+template <bool DAMP, int T>
+__device__ __forceinline__ double rk4_fast(State &s, double vl0, double vlm, double vl1, const Lane &L,
+                                           const Consts &K, Guard &g) {
+  if constexpr (T == TIGHT) return rk4_tight<DAMP>(s, vl0, vlm, vl1, L, K, g);
+  else return rk4_wider<DAMP, T>(s, vl0, vlm, vl1, L, K, g);
 }
 
 __device__ __forceinline__ State initial_state(double dc, const Lane &L, const Consts &K) {

@@ -83,7 +83,7 @@ constexpr int row_len(int st) {  // stage st (0-based, 1..11): its non-zero A en
 
 struct LaneD {
   double inv_dc, kprime, inv_a, b;
-  double a, boa;  // a and b/a: the fast path's folded constants (FastStep)
+  double a, boa, nhboa;  // a, b/a and -b/2a: the fast path's folded constants (FastStep)
 };
 
 // loading velocity V_l(t) = V_ref (1 + exp(-t/20) sin(10 t)), RateStateModel.py:327-329, at a time that is not in the
@@ -174,8 +174,7 @@ template <bool DAMP>
 __device__ __forceinline__ Deriv friction_incr(const Consts &K, const LaneD &L, double theta0, double vl, const Base &b0, double tha,
                                                double rho, GuardD &g, Base &at_point) {
   g.rho = __builtin_fmaxf(g.rho, __builtin_fabsf(hi_as_float(rho)));
-  const double p = __builtin_fma(rho, -0.5, 1.0);
-  const double dlt = __builtin_fma(-L.boa, p * rho, tha);
+  const double dlt = __builtin_fma(-rho, __builtin_fma(rho, L.nhboa, L.boa), tha);  // dmu/a - (b/a)(rho - rho^2/2)
   g.dlt = __builtin_fmaxf(g.dlt, __builtin_fabsf(hi_as_float(dlt)));
   double e = 1.0 / 120.0;
   e = __builtin_fma(e, dlt, 1.0 / 24.0);
@@ -362,11 +361,10 @@ __device__ __forceinline__ bool stages_fast(const Consts &K, const LaneD &L, con
     const double rho = sth;
     g.rho = __builtin_fmaxf(g.rho, __builtin_fabsf(hi_as_float(rho)));
     const double thds = __builtin_fma(F.hd, rho, F.hd);
-    const double p = __builtin_fma(rho, -0.5, 1.0);
+    const double pb = __builtin_fma(rho, L.nhboa, L.boa);
     const double q = __builtin_fma(rho, rho, -rho);
-    const double pr = p * rho;
     const double bq = __builtin_fma(L.boa, q, L.boa);
-    double dlt = __builtin_fma(-L.boa, pr, sm);
+    double dlt = __builtin_fma(-rho, pb, sm);  // (h/a) dmu - (b/a)(rho - rho^2/2)
     const double kvl = F.hk * tv[st];
     P(integral_constant<int, 0>{}, dlt);
     g.dlt = __builtin_fmaxf(g.dlt, __builtin_fabsf(hi_as_float(dlt)));
@@ -602,6 +600,7 @@ __device__ __forceinline__ LaneD make_lane_dp(double dc, double a, double b) {
   L.inv_dc = 1.0 / dc; L.kprime = (1e-2 * 10) / dc; L.inv_a = 1.0 / a; L.b = b;
   L.a = a;
   L.boa = b * L.inv_a;
+  L.nhboa = -0.5 * L.boa;
   return L;
 }
 

@@ -34,9 +34,13 @@ def main():
             c.set_model(m, 1)
             _, ref = c.forward([1000.0])
             data = ref[:, 0] + np.abs(ref[:, 0]) * np.random.default_rng(2025).standard_normal(ref.shape[0])
-            for tag, kw in (("dc_only", {}), ("dc_a_b", dict(a=a, b=b))):
-                sg, ag = g.forward(dc, data=data, want_ssq=True, want_acc=True, **kw)
-                sc, ac = c.forward(dc, data=data, want_ssq=True, want_acc=True, **kw)
+            # "tight": every wave on the TIGHT tier's scaled step (all Dc > 512, rsf_device.h start_tier) — the sampler's
+            # steady state; the random spread above puts a small-Dc lane into every wave, i.e. measures the wider tiers
+            dct = np.sort(np.exp(rng.uniform(np.log(600.0), np.log(3000.0), C)))
+            for tag, kw, dcs in (("dc_only", {}, dc), ("dc_a_b", dict(a=a, b=b), dc), ("tight_dc_only", {}, dct),
+                                 ("tight_dc_a_b", dict(a=a, b=b), dct)):
+                sg, ag = g.forward(dcs, data=data, want_ssq=True, want_acc=True, **kw)
+                sc, ac = c.forward(dcs, data=data, want_ssq=True, want_acc=True, **kw)
                 traj = np.abs(ag - ac).max(axis=0) / np.abs(ac).max(axis=0)
                 ssq = np.abs(sg - sc) / sc
                 out[f"nsteps_{n}_{tag}"] = dict(traj_rel_max=float(traj.max()), traj_rel_median=float(np.median(traj)),
