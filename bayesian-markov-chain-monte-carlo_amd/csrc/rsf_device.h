@@ -111,8 +111,9 @@ __device__ __forceinline__ Lane make_lane(double dc, double a, double b, const C
 
 // Integration state of one lane: ms = mu/k', x = V_ref theta/Dc, V, and the transcendental parts of the RHS at
 // that point:  w = v/V_ref = exp(mu/a - mu_ref/a - (b/a) log x),   rx = 1/x.
-// INSIDE the TIGHT tier's loops rx holds Rh = hhd/x instead (tier_enter / tier_leave): the step-end update
-// 1/x' = (1/x)(1 + q) is indifferent to a constant factor, and the tier's step works on theta derivatives scaled by Rh (rk4_tight).
+// INSIDE the TIGHT tier's loops rx holds Rh = hhd/x instead and x is NOT carried (tier_enter / tier_leave): the step-end
+// update 1/x' = (1/x)(1 + q) is indifferent to a constant factor, the tier's step works on theta derivatives scaled by
+// Rh and never reads x itself (rk4_tight); where x is needed — a resync, a cold trip, leaving the tier — it is hhd / Rh.
 struct State {
   double ms, x, V;
   double w, rx;
@@ -165,11 +166,21 @@ __device__ __forceinline__ void eval_full(double ms, double x, const Lane &L, co
 template <int T>
 __device__ __forceinline__ void tier_enter(State &s, const Lane &L) { if (T == 0) s.rx *= L.hhd; }
 template <int T>
-__device__ __forceinline__ void tier_leave(State &s, const Lane &L) { if (T == 0) s.rx *= L.inv_hhd; }
+__device__ __forceinline__ void tier_x(State &s, const Lane &L) { if (T == 0) s.x = L.hhd * fm::rcp(s.rx); }  // x from Rh
 template <int T>
-__device__ __forceinline__ void eval_full_t(State &s, const Lane &L, const Consts &K) {
+__device__ __forceinline__ void tier_leave(State &s, const Lane &L) {
+  tier_x<T>(s, L);
+  if (T == 0) s.rx *= L.inv_hhd;
+}
+template <int T>
+__device__ __forceinline__ void eval_full_t(State &s, const Lane &L, const Consts &K) {  // from (ms, x)
   eval_full(s.ms, s.x, L, K, s.w, s.rx);
   tier_enter<T>(s, L);
+}
+template <int T>
+__device__ __forceinline__ void resync_t(State &s, const Lane &L, const Consts &K) {  // inside tier T's loop
+  tier_x<T>(s, L);
+  eval_full_t<T>(s, L, K);
 }
 
 // (w', 1/x') at (ms + dms, x1 = x + dx) from (w, rx) at (ms, x).  With rho = dx/x (= dtheta/theta) and
@@ -299,9 +310,8 @@ __device__ __forceinline__ double rk4_cold(State &s, double vl0, double vlm, dou
 // only constants and the previous d1':
 //     Rh x_s = hhd + c_s d1'_prev  (c_s = hhd, hhd, hd),      d1' = Rh - w (Rh x_s),      (beta/x_s) d1 = bh (1 + q) d1',  bh = beta/hhd,
 // so neither rho = R d1 (four products per step) nor Rf, R6 and beta/x_0 (three per step) are formed: 5 instructions
-// fewer than the unscaled form.  x itself is updated once, x' = x (1 + rho_end).  Rounding: Rh is carried by products
-// (resynced every kResync steps), so Rh x_0 = hhd holds to ~1e-15 relative, an ABSOLUTE perturbation of that size on
-// d1 = 1 - w x — 1e-12 of the dtheta/dt ~ 1e-3 of a Dc ~ 1000 lane, inside the Tier-1 figures of DESIGN §4.
+// fewer than the unscaled form.  x itself is not carried at all: Rh IS the state (x = hhd / Rh where a full evaluation
+// needs it), updated once per step, so Rh x_0 = hhd holds by construction.
 template <bool HALF>
 __device__ __forceinline__ void tight_incr(double rho, double dk, const Lane &L, double w0, double &w, double &q, Guard &g) {
   g.rho = __builtin_fmaxf(g.rho, __builtin_fabsf(hi_as_float(rho)));
@@ -350,9 +360,8 @@ __device__ __forceinline__ double rk4_tight(State &s, double vl0, double vlm, do
   const double rho = t1 * (1.0 / 3.0);  // (h/6Dc)/x times the unscaled sum
   tight_incr<false>(rho, L.kh6 * t0, L, s.w, w, q, g);
   s.ms = __builtin_fma(K.h6, t0, s.ms);
-  s.x = __builtin_fma(s.x, rho, s.x);
   s.w = w;
-  s.rx = __builtin_fma(Rh, q, Rh);  // exact to rounding for |rho| < 2^-20; like w, resynced
+  s.rx = __builtin_fma(Rh, q, Rh);  // x' = x (1 + rho), exact to rounding for |rho| < 2^-20; like w, resynced
   return __builtin_fma(2.0, sm, sv);
 }
 
@@ -481,6 +490,7 @@ __device__ __forceinline__ bool trip_fast(const double *v, const Lane &L, const 
 // tier T's representation
 template <bool DAMP, int T, int NU>
 __device__ __forceinline__ void trip_cold(const double *v, const Lane &L, const Consts &K, State &s, double (&dv)[NU]) {
+  tier_x<T>(s, L);
 #pragma unroll 1
   for (int j = 0; j < NU; ++j) {  // one copy of the cold step; its result goes to dv[j] by selects, so that dv stays in registers
     const double r = rk4_cold<DAMP>(s, v[2 * j], v[2 * j + 1], v[2 * j + 2], L, K);
@@ -499,7 +509,7 @@ __device__ __forceinline__ int integrate_pairs(const double *lds, const double *
     const double *v = lds + 2 * r;
     // observations this pair can complete, read before the arithmetic (S > 1: at most one sample per pair)
     const double obs0 = WANT_SSQ ? ld[S1 ? r : em.ko] : 0.0, obs1 = (WANT_SSQ && S1) ? ld[r + 1] : 0.0;
-    if ((r & (kResync - 1)) == 0) eval_full_t<T>(s, L, K);
+    if ((r & (kResync - 1)) == 0) resync_t<T>(s, L, K);
     const State save = s;
     double dv[2];
     const bool bad = trip_fast<DAMP, T, 2>(v, L, K, s, dv);
@@ -545,7 +555,7 @@ __device__ __forceinline__ int integrate_multi(const double *lds, const double *
     double obs[NO], dv[NU];
 #pragma unroll
     for (int j = 0; j < NO; ++j) obs[j] = WANT_SSQ ? ld[S1 ? r + j : min(em.ko + j, kn - 1)] : 0.0;
-    if ((r & (kResync - 1)) == 0) eval_full_t<T>(s, L, K);
+    if ((r & (kResync - 1)) == 0) resync_t<T>(s, L, K);
     const State save = s;
     const bool bad = trip_fast<DAMP, T, NU>(v, L, K, s, dv);
     const unsigned long long badmask = __builtin_amdgcn_ballot_w64(bad);  // wave-uniform, straight from the compares
