@@ -130,6 +130,42 @@ def test_forward_is_scale_free_in_v_ref(gpu_engine, cpu_engine, oracle_mod, inte
         np.testing.assert_allclose(ag, a1 * 1.0e-6, rtol=1e-9, atol=1e-20)
 
 
+@pytest.mark.parametrize("n,substeps,damping,mu_offset", [(500, 1, True, 0.0), (500, 1, False, 0.0), (500, 3, True, 0.0), (2000, 1, True, 0.0),
+                                                           (500, 1, True, 5e-4), (2000, 2, True, -4e-4), (4000, 1, True, 5e-4)])
+def test_forward_tight_tier_and_its_handover(gpu_engine, cpu_engine, oracle_mod, n, substeps, damping, mu_offset):
+    """The sampler's steady state is the TIGHT tier (rsf_device.h rk4_tight: theta derivatives scaled by (h/2Dc)/x, x not
+    carried), chosen per WAVE — the random Dc spreads of the other forward tests put a small-Dc lane into every wave and so
+    only ever run the wider tiers.  Here the waves are homogeneous: every lane inside the tier's a-priori bound
+    (start_tier: 1.2 V_ref h k'/a < 2^-9), four waves well inside and four just inside.  With the reference's constants the
+    guards of such a wave never trip (that is what the bound is for); mu_offset != 0 starts the lanes off their steady state
+    (mu_t_zero is a user-settable attribute, RateStateModel.py:167-184), |1 - v theta/Dc| ~ 4 % puts rho over its guard from the
+    first trip: every chunk starts TIGHT, trips, is redone cold — x rebuilt from the carried (h/2Dc)/x — and hands its rest
+    to the NARROW tier.  Same oracle, same 1e-9."""
+    m = _models(oracle_mod, n, substeps, damping)
+    m.mu_t_zero = m.mu_ref + mu_offset
+    for e in (gpu_engine, cpu_engine):
+        assert e.set_model(m, substeps) == m.nout
+    h = 50.0 / (n - 1) / substeps
+    a0 = 0.011
+    edge = 1.2 * m.V_ref * h * 0.1 / a0 * 512.0  # Dc at which the a-priori bound sits for a = 0.011
+    rng = np.random.default_rng(n + 7 * substeps)
+    inside = np.sort(rng.uniform(1.4 * edge, 6.0 * edge, 256))
+    at_edge = np.sort(rng.uniform(1.005 * edge, 1.12 * edge, 256))
+    dc = np.concatenate([inside, at_edge])
+    a = np.full(dc.shape, a0)
+    b = a + rng.uniform(0.0, 0.006, dc.shape)
+    data = synthetic_data(cpu_engine)
+    for kw in (dict(), dict(a=a, b=b)):
+        sg, ag = gpu_engine.forward(dc, data=data, want_ssq=True, want_acc=True, **kw)
+        sc, ac = cpu_engine.forward(dc, data=data, want_ssq=True, want_acc=True, **kw)
+        assert np.isfinite(sc).all()
+        for lanes in (slice(0, 256), slice(256, 512)):
+            assert _traj_err(ag[:, lanes], ac[:, lanes]) < RTOL
+            np.testing.assert_allclose(sg[lanes], sc[lanes], rtol=RTOL)
+        s2, _ = gpu_engine.forward(dc, data=data, want_ssq=True, want_acc=False, **kw)
+        np.testing.assert_array_equal(s2, sg)
+
+
 def test_forward_random_shapes(gpu_engine, cpu_engine, oracle_mod):
     """Seeded sweep over series lengths and substeps (loop trips of 8, remainders in pairs, odd last step, samples
     completing at any position of a trip, chunk boundaries) with lanes spread over all three tiers."""
