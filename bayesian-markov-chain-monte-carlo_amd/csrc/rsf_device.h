@@ -65,10 +65,10 @@ struct Lane {
   double nhboa;   // -b/2a : (b/a) log1p(rho) = rho (b/a - (b/2a) rho) in the TIGHT tier, two fmas with dlt
   double tc;      // -mu_ref/a
   double hhd, hd, h6d;  // (h/2)/Dc, h/Dc, (h/6)/Dc : theta increments in x units
-  double inv_hhd, bh;   // 1/hhd and beta/hhd: the TIGHT tier carries hhd/x in place of 1/x (rk4_fast)
+  double inv_hhd, bh;   // 1/hhd and beta/hhd: the TIGHT tier carries hhd/x in place of 1/x (rk4_tight)
   double c_l1p;   // leading series coefficients of the active tier, kept in VGPRs (a VOP3 takes one SGPR source and
   double c_em1;   //   the first Horner term has two non-inline constants); see set_tier
-  double c_em1h;  // TIGHT half-step stages: 1/24
+  double c_em1h;  // TIGHT: 1/24, the leading coefficient of its expm1 series
 };
 
 template <int T>
@@ -213,7 +213,7 @@ constexpr float hi_pow2(int e) { return __builtin_bit_cast(float, (1023 + e) << 
 // leading series coefficients of a tier (kept in VGPRs, see Lane)
 template <int T>
 __device__ __forceinline__ void set_tier(Lane &L) {
-  L.c_l1p = T == NARROW ? -1.0 / 6.0 : 1.0 / 7.0;  // (TIGHT needs none: 1 - rho/2 has inline constants only)
+  L.c_l1p = T == NARROW ? -1.0 / 6.0 : 1.0 / 7.0;  // (TIGHT needs none: its log1p is rho (b/a - (b/2a) rho), Lane::nhboa)
   L.c_em1 = 1.0 / 5040.0;  // (TIGHT: 1/24 leads, c_em1h)
   L.c_em1h = 1.0 / 24.0;
   asm volatile("" : "+v"(L.c_l1p), "+v"(L.c_em1), "+v"(L.c_em1h));  // opaque: stays a register value, not re-materialised per step
@@ -275,7 +275,9 @@ __device__ __forceinline__ bool guard_ok(const Guard &g) {  // NaN passes throug
 // evaluations (rk4_cold).  Every kResync steps (w, 1/x) are recomputed in full so rounding in the
 // incremental products cannot accumulate.
 // ---------------------------------------------------------------------------------------------
-constexpr int kResync = 128;  // power of two; every trip length below divides it
+constexpr int kResync = 512;  // power of two; every trip length below divides it.  (128 until round 3: 0.7 instructions per step.
+                              // Four roundings per step on w make 5e-15 relative over 512 steps.)  Not at a chunk's first step: the
+                              // state arrives there from a full evaluation or from the previous chunk's steps, never stale.
 
 // Both step functions return the weighted sum of the V derivatives, k1 + 2 k2 + 2 k3 + k4, IN UNITS OF vk (rhs_tail /
 // rhs_fast): the velocity increment of the step is (h/6) vk = L.h6v times it.  V itself never feeds back into the RHS, so the hot loop does not carry it: with one
@@ -509,7 +511,7 @@ __device__ __forceinline__ int integrate_pairs(const double *lds, const double *
     const double *v = lds + 2 * r;
     // observations this pair can complete, read before the arithmetic (S > 1: at most one sample per pair)
     const double obs0 = WANT_SSQ ? ld[S1 ? r : em.ko] : 0.0, obs1 = (WANT_SSQ && S1) ? ld[r + 1] : 0.0;
-    if ((r & (kResync - 1)) == 0) resync_t<T>(s, L, K);
+    if (r != 0 && (r & (kResync - 1)) == 0) resync_t<T>(s, L, K);
     const State save = s;
     double dv[2];
     const bool bad = trip_fast<DAMP, T, 2>(v, L, K, s, dv);
@@ -555,7 +557,7 @@ __device__ __forceinline__ int integrate_multi(const double *lds, const double *
     double obs[NO], dv[NU];
 #pragma unroll
     for (int j = 0; j < NO; ++j) obs[j] = WANT_SSQ ? ld[S1 ? r + j : min(em.ko + j, kn - 1)] : 0.0;
-    if ((r & (kResync - 1)) == 0) resync_t<T>(s, L, K);
+    if (r != 0 && (r & (kResync - 1)) == 0) resync_t<T>(s, L, K);
     const State save = s;
     const bool bad = trip_fast<DAMP, T, NU>(v, L, K, s, dv);
     const unsigned long long badmask = __builtin_amdgcn_ballot_w64(bad);  // wave-uniform, straight from the compares
