@@ -501,51 +501,62 @@ struct Carry {
 // every kResyncDp-th interval of a chunk the end point is evaluated in full, so rounding cannot accumulate.
 constexpr int kResyncDp = 64;
 
-// one dop853 call (forward in time): y from x to xend.  false on failure.
-// `tab` (LDS, 12 values) holds V_l at the stage times of the STANDARD step of this interval — the first step
-// clipped to h = xend - x, which is what every call after the first interval takes; x and xend are the
-// accumulated grid times shared by all lanes, so the host can tabulate them bit-exactly (rsf_set_model).
-// Any other step (HINIT's first interval, steps after a rejection) evaluates V_l(t) directly.
+// Whether a lane's carried step size reaches past xend, i.e. its next step is the tabulated standard step h = xend - x
+// (dop853.f's `last` on the first pass of its loop, after the too-small-step test).
+__device__ __forceinline__ bool takes_standard_step(const Carry &c, double x, double xend) {
+  constexpr double uround = 2.3e-16;
+  return c.have_kf && (x + 1.01 * c.hc - xend > 0.0) && !(0.1 * fabs(c.hc) <= fabs(x) * uround);
+}
+
+// The steady state of every call after the first interval: EVERY lane of the wave takes the tabulated step (the caller has
+// tested takes_standard_step for all of them) and all accept it.  Two wave-uniform tests instead of the general loop's six
+// per-lane branches (each of which a lone wave sits out for the latency of its compare).  → true: the state is at xend;
+// false (wave-uniform): a lane left the series' range or rejected — nothing was touched, the interval goes to call_general.
+// `tab` (LDS, 12 values) holds V_l at the stage times of the standard step of this interval; x and xend are the accumulated
+// grid times shared by all lanes, so the host can tabulate them bit-exactly (rsf_set_model).
 template <bool DAMP>
-__device__ __forceinline__ bool call(const Consts &K, const LaneD &L, const double *tab, double &x, double xend, double y[3], Carry &c,
-                                     bool resync) {  // resync: wave-uniform
+__device__ __forceinline__ bool fast_interval(const Consts &K, const LaneD &L, const double *tab, double &x, double xend, double y[3],
+                                              Carry &c, bool resync) {  // resync: wave-uniform
+  constexpr double safe = 0.9, facc1 = 1.0 / 0.3, facc2 = 1.0 / 6.0;
+  double km[12], kt[12], k5[3], ssum[3], closing[kClosingLen], fac11;
+  VSums vs;
+  const Base b0 = c.bf;  // slip rate and 1/theta at (x, y): the stages of the step are evaluated incrementally from it
+  const double hs = xend - x;
+  km[0] = c.kf.m; kt[0] = c.kf.t; vs.k1 = c.kf.v;
+  const bool bad = stages_fast<DAMP>(K, L, tab, hs, y, km, kt, b0, vs, closing);
+  const double err = closing_fast(L, y, km, kt, vs, closing, k5, fac11, ssum);
+  if (!__all(!bad && err <= 1.0)) return false;
+  // first-same-as-last, at xend
+  bool full = resync;
+  if (!full) {
+    GuardD g = {0.0f, 0.0f};
+    c.kf = friction_incr<DAMP>(K, L, y[1], tab[11], b0, ssum[0], ssum[1], g, c.bf);
+    full = __any(guard_tripped(g));
+  }
+  if (full) c.kf = friction<DAMP>(K, L, tab[11], k5[0], k5[1], c.bf);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) y[i] = k5[i];
+  x = x + hs;
+  c.hc = hs * __builtin_amdgcn_rcp(fmax(facc2, fmin(facc1, fac11 * (1.0 / safe))));  // (a prediction: closing_fast)
+  return true;
+}
+
+// one dop853 call (forward in time) through the general loop: y from x to xend.  false on failure.
+// HINIT's first interval, steps after a rejection, stiff small-Dc lanes.  The first step of a call whose carried step size
+// reaches past xend is the tabulated one (`tab`); any other evaluates V_l(t) directly.
+template <bool DAMP>
+__device__ __forceinline__ bool call_general(const Consts &K, const LaneD &L, const double *tab, double &x, double xend, double y[3],
+                                             Carry &c) {
   constexpr double safe = 0.9, facc1 = 1.0 / 0.3, facc2 = 1.0 / 6.0, uround = 2.3e-16;
   const double hmax = fabs(xend - x);
-  double km[12], kt[12], k5[3], ssum[3], closing[kClosingLen];
+  double km[12], kt[12], k5[3];
   VSums vs;
   double h = c.hc;
   bool last = false, reject = false;
-  Base b0 = c.bf;  // slip rate and 1/theta at (x, y): the stages of a step are evaluated incrementally from it
+  Base b0 = c.bf;
   Deriv k1 = c.kf;
   if (!c.have_kf) k1 = friction<DAMP>(K, L, tab[0], y[0], y[1], b0);  // V_l(x): x is the interval's start time for every lane
   if (h == 0.0) h = hinit<DAMP>(K, L, x, y, k1, hmax);
-  // Fast path, the steady state of every call after the first interval: the carried step size reaches past xend for
-  // EVERY lane of the wave, so all take the tabulated step h = xend - x, and all accept it.  Two wave-uniform tests
-  // instead of the general loop's six per-lane branches (each of which a lone wave sits out for the latency of its
-  // compare).  Anything else — a lane that wants a smaller step, leaves the series' range or rejects — falls through
-  // to the general loop, which starts again from the untouched (x, y, k1).
-  if (__all(c.have_kf && (x + 1.01 * h - xend > 0.0) && !(0.1 * fabs(h) <= fabs(x) * uround))) {
-    const double hs = xend - x;
-    double fac11;
-    km[0] = k1.m; kt[0] = k1.t; vs.k1 = k1.v;
-    const bool bad = stages_fast<DAMP>(K, L, tab, hs, y, km, kt, b0, vs, closing);
-    const double err = closing_fast(L, y, km, kt, vs, closing, k5, fac11, ssum);
-    if (__all(!bad && err <= 1.0)) {
-      // first-same-as-last, at xend
-      bool full = resync;
-      if (!full) {
-        GuardD g = {0.0f, 0.0f};
-        c.kf = friction_incr<DAMP>(K, L, y[1], tab[11], b0, ssum[0], ssum[1], g, c.bf);
-        full = __any(guard_tripped(g));
-      }
-      if (full) c.kf = friction<DAMP>(K, L, tab[11], k5[0], k5[1], c.bf);
-#pragma unroll
-      for (int i = 0; i < 3; ++i) y[i] = k5[i];
-      x = x + hs;
-      c.hc = hs * __builtin_amdgcn_rcp(fmax(facc2, fmin(facc1, fac11 * (1.0 / safe))));  // (a prediction: closing_fast)
-      return true;
-    }
-  }
   for (int nstep = 0;;) {
     if (nstep > 500) return false;
     if (0.1 * fabs(h) <= fabs(x) * uround) return false;
@@ -579,6 +590,14 @@ __device__ __forceinline__ bool call(const Consts &K, const LaneD &L, const doub
     }
     h = hnew;
   }
+}
+
+// one dop853 call: the steady-state step if every lane of the wave takes it, else the general loop
+template <bool DAMP>
+__device__ __forceinline__ bool call(const Consts &K, const LaneD &L, const double *tab, double &x, double xend, double y[3], Carry &c,
+                                     bool resync) {
+  if (__all(takes_standard_step(c, x, xend)) && fast_interval<DAMP>(K, L, tab, x, xend, y, c, resync)) return true;
+  return call_general<DAMP>(K, L, tab, x, xend, y, c);
 }
 
 // LDS chunk of the DOP853 mode: [ 12 loading values per interval : 12*kc ][ data : kc ]
@@ -628,20 +647,34 @@ __device__ __forceinline__ double solve(double *lds, const Consts &K, bool resid
     const int kn = min(K.kc, K.nout - k0);
     if (!resident) stage_chunk_dp(lds, K, k0, kn);
     if (!active) continue;
-    for (int kk = 0; kk < kn; ++kk) {
-      double ak = 0.0;  // after a failed call the reference's arrays keep their zeros (RateStateModel.py:361-381)
-      double obs = WANT_SSQ ? ld[kk] : 0.0;  // read ahead of the call: its LDS latency passes under the step
-      if (!failed) {
-        failed = !call<DAMP>(K, L, lds + kTab * kk, x, x + delta_t, y, c, (kk & (kResyncDp - 1)) == kResyncDp - 1);
-        ak = (y[2] - vprev) * inv_dt;
-        vprev = y[2];
-      }
+    auto sample = [&](int kk, double ak, double obs) {
       if (WANT_ACC) acc_out[(int64_t)(k0 + kk) * stride] = ak;
       if (WANT_SSQ) {
-        asm volatile("" : "+v"(obs));
         const double r = ak - obs;
         ssq = __builtin_fma(r, r, ssq);
       }
+    };
+    for (int kk = 0; kk < kn;) {
+      // the steady state: a loop of its own that holds nothing but the tabulated step, so that its registers and exec
+      // masks are not merged with the general loop's at every interval (that bookkeeping was ~50 instructions per interval)
+      while (kk < kn && __all(!failed && takes_standard_step(c, x, x + delta_t))) {
+        double obs = WANT_SSQ ? ld[kk] : 0.0;  // read ahead of the step: its LDS latency passes under it
+        if (!fast_interval<DAMP>(K, L, lds + kTab * kk, x, x + delta_t, y, c, (kk & (kResyncDp - 1)) == kResyncDp - 1)) break;
+        const double ak = (y[2] - vprev) * inv_dt;
+        vprev = y[2];
+        asm volatile("" : "+v"(obs));
+        sample(kk, ak, obs);
+        ++kk;
+      }
+      if (kk >= kn) break;
+      double ak = 0.0;  // after a failed call the reference's arrays keep their zeros (RateStateModel.py:361-381)
+      if (!failed) {
+        failed = !call_general<DAMP>(K, L, lds + kTab * kk, x, x + delta_t, y, c);
+        ak = (y[2] - vprev) * inv_dt;
+        vprev = y[2];
+      }
+      sample(kk, ak, WANT_SSQ ? ld[kk] : 0.0);
+      ++kk;
     }
   }
   return ssq;

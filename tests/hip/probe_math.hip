@@ -41,7 +41,7 @@ int main(int argc, char **argv) {
   fclose(f);
   double *din, *dout;
   if (hipMalloc(&din, bytes) != hipSuccess || hipMalloc(&dout, bytes) != hipSuccess) return 4;
-  hipMemcpy(din, h.data(), bytes, hipMemcpyHostToDevice);
+  (void)hipMemcpy(din, h.data(), bytes, hipMemcpyHostToDevice);
   hipLaunchKernelGGL(probe, dim3((n + 255) / 256), dim3(256), 0, nullptr, kind, n, din, dout);
   if (hipMemcpy(o.data(), dout, bytes, hipMemcpyDeviceToHost) != hipSuccess) return 4;
   f = fopen(argv[3], "wb");
