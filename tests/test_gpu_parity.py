@@ -441,6 +441,36 @@ def test_dop853_mode_matches_oracle_and_reference(gpu_engine, cpu_engine, oracle
         np.testing.assert_allclose(V[0, 0, 0], c["vstart"], rtol=1e-5, err_msg=name)
 
 
+def test_dop853_failed_calls_leave_zeros(gpu_engine, cpu_engine, oracle_mod):
+    """A dop853 call that fails (step size underflow on a NaN, > 500 steps) ends the reference's loop — `while r.successful()`,
+    RateStateModel.py:361-381 — and the rest of its arrays keep their zeros.  Lanes that fail in their second call share
+    waves with healthy ones: the wave then leaves the steady-state loop for good (solve() in rsf_device_dop853.h) and every
+    later interval of its healthy lanes goes through the general loop — same results, to the mode's 1e-9."""
+    m = _dp(oracle_mod, 300)
+    for e in (gpu_engine, cpu_engine):
+        assert e.set_model(m, 1) == m.nout
+    bad = [(1000.0, 1e-9, 1e-3), (1e-4, 1e-9, 1e-3), (1e-6, 1e-4, 0.5), (1e-12, 0.011, 5.0)]
+    rng = np.random.default_rng(8)
+    C = 160  # two full waves and a ragged one
+    dc, a, b = rng.uniform(400.0, 3000.0, C), np.full(C, 0.011), np.full(C, 0.014)
+    where = [3, 64 + 17, 64 + 40, 128 + 5]  # wave 0: one failing lane, wave 1: two, wave 2 (ragged): one
+    for i, (d_, a_, b_) in zip(where, bad):
+        dc[i], a[i], b[i] = d_, a_, b_
+    data = synthetic_data(cpu_engine)
+    sg, ag = gpu_engine.forward(dc, a=a, b=b, data=data, want_ssq=True, want_acc=True)
+    sc, ac = cpu_engine.forward(dc, a=a, b=b, data=data, want_ssq=True, want_acc=True)
+    ok = np.ones(C, bool)
+    ok[where] = False
+    assert _traj_err(ag[:, ok], ac[:, ok]) < RTOL
+    np.testing.assert_allclose(sg[ok], sc[ok], rtol=RTOL)
+    for i in where:
+        assert np.count_nonzero(ac[2:, i]) == 0, "the fixture lanes are meant to fail in their second call"
+        np.testing.assert_array_equal(ag[2:, i], 0.0)
+        # the one sample such a lane completes: a = 1e-9 amplifies the rounding of its exponent's argument a millionfold
+        np.testing.assert_allclose(ag[:2, i], ac[:2, i], rtol=1e-5, atol=1e-300)
+        np.testing.assert_allclose(sg[i], sc[i], rtol=1e-5)
+
+
 @pytest.mark.parametrize("tag", ["list", "dict", "dict3", "tightbox"])
 def test_dop853_mode_replays_the_reference_chain(gpu_engine, golden, oracle_mod, tag):
     """Same variates + same integrator: the GPU kernel walks the reference's chain, every iteration."""
