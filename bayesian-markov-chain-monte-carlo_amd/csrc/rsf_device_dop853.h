@@ -449,13 +449,12 @@ __device__ __forceinline__ double solution_and_error(double h, const double y[3]
 //         = E5 / sqrt(3 (E5 + 0.01 E3)),   E5 = sum (e5'_i w_i)^2,  E3 = sum (e3'_i w_i)^2.
 // Here the step IS the output interval whatever the controller says, and the carried prediction is only compared with it
 // (x + 1.01 h > xend), so the hardware's approximate reciprocal / reciprocal square root / square root (v_rcp_f64,
-// v_rsq_f64, v_sqrt_f64: ~1e-7 relative, one instruction each) stand in for dop853.f's divisions, sqrt and pow:
-// err ** (1/8) is three square roots.  A prediction that ends the steady state enters the general loop as a step size
-// 1e-7 off — a perturbation of the solution ~1e-7 times a local error.  Constants: the closing row of kStepTable, loaded
+// v_rsq_f64, v_sqrt_f64: ~1e-7 relative, one instruction each) stand in for dop853.f's divisions, sqrt and pow
+// (predicted_step: err ** (1/8) is three square roots).  A prediction that ends the steady state enters the general loop
+// as a step size 1e-7 off — a perturbation of the solution ~1e-7 times a local error.  Constants: the closing row of kStepTable, loaded
 // during the last stage.  s[0], s[1] are left for the end point's evaluation (they are its series arguments).
 __device__ __forceinline__ double closing_fast(const LaneD &L, const double y[3], const double (&km)[12], const double (&kt)[12],
-                                               const VSums &vs, const double (&w)[kClosingLen], double k5[3], double &fac11,
-                                               double (&s)[3]) {
+                                               const VSums &vs, const double (&w)[kClosingLen], double k5[3], double (&s)[3]) {
   double e5[3] = {0.0, 0.0, vs.e5}, e3[3];
   s[0] = 0.0; s[1] = 0.0; s[2] = vs.s;
 #pragma unroll
@@ -480,9 +479,7 @@ __device__ __forceinline__ double closing_fast(const LaneD &L, const double y[3]
   }
   double deno = err + 0.01 * err2;
   if (deno <= 0.0) deno = 1.0;
-  err = err * __builtin_amdgcn_rsq(3.0 * deno);
-  fac11 = __builtin_amdgcn_sqrt(__builtin_amdgcn_sqrt(__builtin_amdgcn_sqrt(err)));  // 0 stays 0, NaN stays NaN
-  return err;
+  return err * __builtin_amdgcn_rsq(3.0 * deno);
 }
 
 // What a call hands to the next one: the carried step size (0 => HINIT), and the derivative and (v, 1/theta) at (x, y)
@@ -514,18 +511,32 @@ __device__ __forceinline__ bool takes_standard_step(const Carry &c, double x, do
 // false (wave-uniform): a lane left the series' range or rejected — nothing was touched, the interval goes to call_general.
 // `tab` (LDS, 12 values) holds V_l at the stage times of the standard step of this interval; x and xend are the accumulated
 // grid times shared by all lanes, so the host can tabulate them bit-exactly (rsf_set_model).
+// The step size dop853.f would carry out of an accepted step of size hs with error norm err: hs / max(facc2, min(facc1,
+// err^(1/8) / safe)).  The steady state never forms it: all it would be used for there is takes_standard_step of the next
+// interval, 1.01 hs / fac > hs, i.e. fac < 1.01, i.e. err < (1.01 safe)^8 — one compare on the error norm instead of
+// three v_sqrt_f64, a v_rcp_f64 and four more operations per interval.  It is formed where the steady state ends.
+constexpr double kSafe = 0.9, kFacc1 = 1.0 / 0.3, kFacc2 = 1.0 / 6.0;
+constexpr double kErrStandard = (1.01 * kSafe) * (1.01 * kSafe) * (1.01 * kSafe) * (1.01 * kSafe) * (1.01 * kSafe) * (1.01 * kSafe) *
+                                (1.01 * kSafe) * (1.01 * kSafe);
+__device__ __forceinline__ double predicted_step(double hs, double err) {  // (a prediction: the approximate forms of closing_fast)
+  const double fac11 = __builtin_amdgcn_sqrt(__builtin_amdgcn_sqrt(__builtin_amdgcn_sqrt(err)));  // 0 stays 0, NaN stays NaN
+  return hs * __builtin_amdgcn_rcp(fmax(kFacc2, fmin(kFacc1, fac11 * (1.0 / kSafe))));
+}
+
+// On acceptance err / hs return the step's error norm and size (for predicted_step); c.hc is NOT updated.
 template <bool DAMP>
 __device__ __forceinline__ bool fast_interval(const Consts &K, const LaneD &L, const double *tab, double &x, double xend, double y[3],
-                                              Carry &c, bool resync) {  // resync: wave-uniform
-  constexpr double safe = 0.9, facc1 = 1.0 / 0.3, facc2 = 1.0 / 6.0;
-  double km[12], kt[12], k5[3], ssum[3], closing[kClosingLen], fac11;
+                                              Carry &c, bool resync, double &err, double &hs) {  // resync: wave-uniform
+  double km[12], kt[12], k5[3], ssum[3], closing[kClosingLen];
   VSums vs;
   const Base b0 = c.bf;  // slip rate and 1/theta at (x, y): the stages of the step are evaluated incrementally from it
-  const double hs = xend - x;
+  const double h1 = xend - x;
   km[0] = c.kf.m; kt[0] = c.kf.t; vs.k1 = c.kf.v;
-  const bool bad = stages_fast<DAMP>(K, L, tab, hs, y, km, kt, b0, vs, closing);
-  const double err = closing_fast(L, y, km, kt, vs, closing, k5, fac11, ssum);
-  if (!__all(!bad && err <= 1.0)) return false;
+  const bool bad = stages_fast<DAMP>(K, L, tab, h1, y, km, kt, b0, vs, closing);
+  const double e1 = closing_fast(L, y, km, kt, vs, closing, k5, ssum);
+  if (!__all(!bad && e1 <= 1.0)) return false;
+  err = e1;
+  hs = h1;
   // first-same-as-last, at xend
   bool full = resync;
   if (!full) {
@@ -536,8 +547,7 @@ __device__ __forceinline__ bool fast_interval(const Consts &K, const LaneD &L, c
   if (full) c.kf = friction<DAMP>(K, L, tab[11], k5[0], k5[1], c.bf);
 #pragma unroll
   for (int i = 0; i < 3; ++i) y[i] = k5[i];
-  x = x + hs;
-  c.hc = hs * __builtin_amdgcn_rcp(fmax(facc2, fmin(facc1, fac11 * (1.0 / safe))));  // (a prediction: closing_fast)
+  x = x + h1;
   return true;
 }
 
@@ -547,7 +557,7 @@ __device__ __forceinline__ bool fast_interval(const Consts &K, const LaneD &L, c
 template <bool DAMP>
 __device__ __forceinline__ bool call_general(const Consts &K, const LaneD &L, const double *tab, double &x, double xend, double y[3],
                                              Carry &c) {
-  constexpr double safe = 0.9, facc1 = 1.0 / 0.3, facc2 = 1.0 / 6.0, uround = 2.3e-16;
+  constexpr double safe = kSafe, facc1 = kFacc1, facc2 = kFacc2, uround = 2.3e-16;
   const double hmax = fabs(xend - x);
   double km[12], kt[12], k5[3];
   VSums vs;
@@ -596,7 +606,11 @@ __device__ __forceinline__ bool call_general(const Consts &K, const LaneD &L, co
 template <bool DAMP>
 __device__ __forceinline__ bool call(const Consts &K, const LaneD &L, const double *tab, double &x, double xend, double y[3], Carry &c,
                                      bool resync) {
-  if (__all(takes_standard_step(c, x, xend)) && fast_interval<DAMP>(K, L, tab, x, xend, y, c, resync)) return true;
+  double err, hs;
+  if (__all(takes_standard_step(c, x, xend)) && fast_interval<DAMP>(K, L, tab, x, xend, y, c, resync, err, hs)) {
+    c.hc = predicted_step(hs, err);
+    return true;
+  }
   return call_general<DAMP>(K, L, tab, x, xend, y, c);
 }
 
@@ -656,15 +670,24 @@ __device__ __forceinline__ double solve(double *lds, const Consts &K, bool resid
     };
     for (int kk = 0; kk < kn;) {
       // the steady state: a loop of its own that holds nothing but the tabulated step, so that its registers and exec
-      // masks are not merged with the general loop's at every interval (that bookkeeping was ~50 instructions per interval)
-      while (kk < kn && __all(!failed && takes_standard_step(c, x, x + delta_t))) {
-        double obs = WANT_SSQ ? ld[kk] : 0.0;  // read ahead of the step: its LDS latency passes under it
-        if (!fast_interval<DAMP>(K, L, lds + kTab * kk, x, x + delta_t, y, c, (kk & (kResyncDp - 1)) == kResyncDp - 1)) break;
-        const double ak = (y[2] - vprev) * inv_dt;
-        vprev = y[2];
-        asm volatile("" : "+v"(obs));
-        sample(kk, ak, obs);
-        ++kk;
+      // masks are not merged with the general loop's at every interval (that bookkeeping was ~50 instructions per interval).
+      // Entered on the carried step size; continued on the error norm alone (kErrStandard); the carried step size is
+      // formed when it ends.
+      if (__all(!failed && takes_standard_step(c, x, x + delta_t))) {
+        double err = -1.0, hs = 0.0;
+        bool took;
+        do {
+          double obs = WANT_SSQ ? ld[kk] : 0.0;  // read ahead of the step: its LDS latency passes under it
+          took = fast_interval<DAMP>(K, L, lds + kTab * kk, x, x + delta_t, y, c, (kk & (kResyncDp - 1)) == kResyncDp - 1, err, hs);
+          if (!took) break;
+          const double ak = (y[2] - vprev) * inv_dt;
+          vprev = y[2];
+          asm volatile("" : "+v"(obs));
+          sample(kk, ak, obs);
+          ++kk;
+        } while (kk < kn && __all(err < kErrStandard));
+        if (err >= 0.0) c.hc = predicted_step(hs, err);
+        if (took) continue;  // (the next interval decides again, on the step size just formed)
       }
       if (kk >= kn) break;
       double ak = 0.0;  // after a failed call the reference's arrays keep their zeros (RateStateModel.py:361-381)
