@@ -23,6 +23,8 @@ def main():
     ap.add_argument("--lanes", type=int, default=262144)
     ap.add_argument("--nsteps", type=int, default=2000)
     ap.add_argument("--rounds", type=int, default=5)
+    ap.add_argument("--dc", type=float, nargs=2, default=[800.0, 1200.0],
+                    help="Dc range of the lanes: below ~560 (nsteps 500) / ~140 (nsteps 2000) the NARROW tier runs, below a quarter of that WIDE")
     args = ap.parse_args()
 
     import torch
@@ -32,8 +34,8 @@ def main():
 
     model, data = synthetic_problem(args.nsteps)
     C = args.lanes
-    dc = torch.linspace(800.0, 1200.0, C, dtype=torch.float64, device="cuda")
-    out = {"lanes": C, "nsteps": args.nsteps}
+    dc = torch.linspace(args.dc[0], args.dc[1], C, dtype=torch.float64, device="cuda")
+    out = {"lanes": C, "nsteps": args.nsteps, "dc": args.dc}
     with rsf.Engine(mem="device") as e:
         nout = e.set_model(model, 1)
         for name, kw in (("ssq_only", dict(data=data, want_ssq=True, want_acc=False)), ("trajectory", dict(want_acc=True))):
