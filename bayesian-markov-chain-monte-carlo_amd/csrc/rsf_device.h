@@ -162,15 +162,17 @@ __device__ __forceinline__ void eval_full(double ms, double x, const Lane &L, co
   rx = fm::rcp(x);
 }
 
-// the TIGHT tier's representation of 1/x (struct State)
+enum Tier : int { TIGHT = 0, NARROW = 1, WIDE = 2 };
+
+// the TIGHT and NARROW tiers' representation of 1/x (struct State)
 template <int T>
-__device__ __forceinline__ void tier_enter(State &s, const Lane &L) { if (T == 0) s.rx *= L.hhd; }
+__device__ __forceinline__ void tier_enter(State &s, const Lane &L) { if (T != WIDE) s.rx *= L.hhd; }
 template <int T>
-__device__ __forceinline__ void tier_x(State &s, const Lane &L) { if (T == 0) s.x = L.hhd * fm::rcp(s.rx); }  // x from Rh
+__device__ __forceinline__ void tier_x(State &s, const Lane &L) { if (T != WIDE) s.x = L.hhd * fm::rcp(s.rx); }  // x from Rh
 template <int T>
 __device__ __forceinline__ void tier_leave(State &s, const Lane &L) {
   tier_x<T>(s, L);
-  if (T == 0) s.rx *= L.inv_hhd;
+  if (T != WIDE) s.rx *= L.inv_hhd;
 }
 template <int T>
 __device__ __forceinline__ void eval_full_t(State &s, const Lane &L, const Consts &K) {  // from (ms, x)
@@ -189,7 +191,7 @@ __device__ __forceinline__ void resync_t(State &s, const Lane &L, const Consts &
 //   tier     |rho| <   |dlt| <   log1p to     expm1 to       1/x'                              truncation
 //   TIGHT    2^-20     2^-9      rho^2/2      dlt^4/24       1 - rho + rho^2 (no Newton step)  rho^3 < 2^-60; expm1: < 2.4e-16 at the
 //            (its two half-step stages: |dlt| < 2^-10, truncation < 8e-18 relative)              guard's edge (1 ulp), 8e-18 at |dlt| = 1e-3
-//   NARROW   2^-9      2^-6      rho^6/6      dlt^7/5040     2nd-order start + 1 Newton step   < 1e-19, rho^6 < 2^-54
+//   NARROW   2^-14     2^-7      rho^3/3      dlt^6/720      1 - rho + rho^2 - rho^3 (none)    rho^4 < 2^-56; expm1: < 4.5e-17
 //   WIDE     2^-7      2^-6      rho^7/7      dlt^7/5040     1st-order start + 2 Newton steps  < 1e-19, rho^8 < 2^-56
 // Guard tracks the largest |rho| / |dlt| seen since it was last reset — through the HIGH WORD of each double read as
 // a float: for |x| < 2^1017 that reading is finite and monotone in |x|, the thresholds are powers of two (exact in the
@@ -199,7 +201,6 @@ __device__ __forceinline__ void resync_t(State &s, const Lane &L, const Consts &
 // come out of a state that is already beyond 1e150 — whose sum of squares rejects the proposal whichever path
 // integrates it.  (Testing w for Inf at the end of the pair instead put five dependent instructions between the last
 // result and the loop branch: +3 % at cfg1.)
-enum Tier : int { TIGHT = 0, NARROW = 1, WIDE = 2 };
 
 struct Guard {
   float rho, dlt;
@@ -213,27 +214,24 @@ constexpr float hi_pow2(int e) { return __builtin_bit_cast(float, (1023 + e) << 
 // leading series coefficients of a tier (kept in VGPRs, see Lane)
 template <int T>
 __device__ __forceinline__ void set_tier(Lane &L) {
-  L.c_l1p = T == NARROW ? -1.0 / 6.0 : 1.0 / 7.0;  // (TIGHT needs none: its log1p is rho (b/a - (b/2a) rho), Lane::nhboa)
-  L.c_em1 = 1.0 / 5040.0;  // (TIGHT: 1/24 leads, c_em1h)
+  // TIGHT: log1p needs none (rho (b/a - (b/2a) rho), Lane::nhboa), expm1 leads with 1/24;  NARROW: (b/3a) rho^2 more and 1/720;
+  // WIDE: the unscaled series of eval_incr
+  L.c_l1p = T == NARROW ? L.boa * (1.0 / 3.0) : 1.0 / 7.0;
+  L.c_em1 = T == NARROW ? 1.0 / 720.0 : 1.0 / 5040.0;
   L.c_em1h = 1.0 / 24.0;
   asm volatile("" : "+v"(L.c_l1p), "+v"(L.c_em1), "+v"(L.c_em1h));  // opaque: stays a register value, not re-materialised per step
 }
 
-// the NARROW / WIDE form (the TIGHT tier has its own, tight_incr)
+// the WIDE tier's form (TIGHT and NARROW work on scaled derivatives: tight_incr)
 template <int T>
 __device__ __forceinline__ void eval_incr(double kf, double dms_dt, double R, double dth_dt, double x1, const Lane &L, double w0,
                                           double rx0, double &w, double &rx, Guard &g) {
-  static_assert(T == NARROW || T == WIDE, "");
+  static_assert(T == WIDE, "");
   // dk = kf * dms_dt (kf: kia times the step fraction);  rho = R * dth_dt (R: step fraction / Dc / x, once per step)
   const double rho = dth_dt * R;
   g.rho = __builtin_fmaxf(g.rho, __builtin_fabsf(hi_as_float(rho)));
-  double p;
-  if (T == WIDE) {
-    p = fm::hfma(L.c_l1p, rho, -1.0 / 6.0);
-    p = fm::hfma(p, rho, 1.0 / 5.0);
-  } else {
-    p = fm::hfma(L.c_l1p, rho, 1.0 / 5.0);
-  }
+  double p = fm::hfma(L.c_l1p, rho, -1.0 / 6.0);
+  p = fm::hfma(p, rho, 1.0 / 5.0);
   p = fm::hfma(p, rho, -1.0 / 4.0);
   p = fm::hfma(p, rho, 1.0 / 3.0);
   p = __builtin_fma(p, rho, -0.5);
@@ -247,20 +245,15 @@ __device__ __forceinline__ void eval_incr(double kf, double dms_dt, double R, do
   e = __builtin_fma(e, dlt, 0.5);
   e = __builtin_fma(e, dlt, 1.0);
   w = __builtin_fma(w0 * dlt, e, w0);  // w0*dlt is off the critical path (e is the late operand)
-  if (T == WIDE) {
-    rx = __builtin_fma(-rho, rx0, rx0);
-    rx = __builtin_fma(rx, __builtin_fma(-x1, rx, 1.0), rx);
-    rx = __builtin_fma(rx, __builtin_fma(-x1, rx, 1.0), rx);
-  } else {
-    rx = __builtin_fma(rx0, __builtin_fma(rho, rho, -rho), rx0);
-    rx = __builtin_fma(rx, __builtin_fma(-x1, rx, 1.0), rx);
-  }
+  rx = __builtin_fma(-rho, rx0, rx0);
+  rx = __builtin_fma(rx, __builtin_fma(-x1, rx, 1.0), rx);
+  rx = __builtin_fma(rx, __builtin_fma(-x1, rx, 1.0), rx);
 }
 
 template <int T>
 __device__ __forceinline__ bool guard_ok(const Guard &g) {  // NaN passes through (see Guard)
-  return (g.rho < (T == WIDE ? hi_pow2(-7) : (T == NARROW ? hi_pow2(-9) : hi_pow2(-20)))) &&
-         (g.dlt < (T == TIGHT ? hi_pow2(-9) : hi_pow2(-6))) && (T != TIGHT || g.dlt_h < hi_pow2(-10));
+  return (g.rho < (T == WIDE ? hi_pow2(-7) : (T == NARROW ? hi_pow2(-14) : hi_pow2(-20)))) &&
+         (g.dlt < (T == TIGHT ? hi_pow2(-9) : (T == NARROW ? hi_pow2(-7) : hi_pow2(-6)))) && (T != TIGHT || g.dlt_h < hi_pow2(-10));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -314,18 +307,33 @@ __device__ __forceinline__ double rk4_cold(State &s, double vl0, double vlm, dou
 // so neither rho = R d1 (four products per step) nor Rf, R6 and beta/x_0 (three per step) are formed: 5 instructions
 // fewer than the unscaled form.  x itself is not carried at all: Rh IS the state (x = hhd / Rh where a full evaluation
 // needs it), updated once per step, so Rh x_0 = hhd holds by construction.
-template <bool HALF>
+//
+// The NARROW tier is the same step with one more term in each series — log1p to rho^3/3, expm1 to dlt^6/720,
+// 1/x' = (1/x)(1 - rho + rho^2 - rho^3) — which carries it to |rho| < 2^-14, |dlt| < 2^-7 (truncations 4.5e-18, 4.5e-17, 1.4e-17):
+// four instructions more per evaluation.  (Until round 3 it was the unscaled form with Newton steps on 1/x that the WIDE
+// tier still uses: 131 instructions per step against 101, and its a-priori bound reached less far down in Dc.)
+template <int T, bool HALF>
 __device__ __forceinline__ void tight_incr(double rho, double dk, const Lane &L, double w0, double &w, double &q, Guard &g) {
+  static_assert(T == TIGHT || T == NARROW, "");
   g.rho = __builtin_fmaxf(g.rho, __builtin_fabsf(hi_as_float(rho)));
-  const double dlt = __builtin_fma(-rho, __builtin_fma(rho, L.nhboa, L.boa), dk);  // dk - (b/a)(rho - rho^2/2)
-  // expm1 to dlt^4/24 at every stage: half-step stages are held to |dlt| < 2^-10, the others to 2^-9
-  if (HALF) g.dlt_h = __builtin_fmaxf(g.dlt_h, __builtin_fabsf(hi_as_float(dlt)));
+  double pb = T == NARROW ? __builtin_fma(rho, L.c_l1p, L.nhboa) : L.nhboa;  // (b/a)(1 - rho/2 [+ rho^2/3])
+  const double dlt = __builtin_fma(-rho, __builtin_fma(rho, pb, L.boa), dk);
+  // TIGHT: expm1 to dlt^4/24 at every stage, half-step stages held to |dlt| < 2^-10, the others to 2^-9
+  if (T == TIGHT && HALF) g.dlt_h = __builtin_fmaxf(g.dlt_h, __builtin_fabsf(hi_as_float(dlt)));
   else g.dlt = __builtin_fmaxf(g.dlt, __builtin_fabsf(hi_as_float(dlt)));
-  double e = fm::hfma(L.c_em1h, dlt, 1.0 / 6.0);
+  double e;
+  if (T == NARROW) {
+    e = fm::hfma(L.c_em1, dlt, 1.0 / 120.0);
+    e = fm::hfma(e, dlt, 1.0 / 24.0);
+    e = fm::hfma(e, dlt, 1.0 / 6.0);
+  } else {
+    e = fm::hfma(L.c_em1h, dlt, 1.0 / 6.0);
+  }
   e = __builtin_fma(e, dlt, 0.5);
   e = __builtin_fma(e, dlt, 1.0);
   w = __builtin_fma(w0 * dlt, e, w0);
-  q = __builtin_fma(rho, rho, -rho);  // 1/x' = (1/x)(1 + q)
+  const double r1 = __builtin_fma(rho, rho, -rho);                 // -rho + rho^2
+  q = T == NARROW ? __builtin_fma(-rho, r1, -rho) : r1;             // 1/x' = (1/x)(1 + q);  NARROW: -rho + rho^2 - rho^3
 }
 
 // d0 = V_l - V_ref w,  d1' = Rh - w xr  (xr = Rh x at the stage),  g = d0 - brx d1'  (brx = bh (1 + q)) and the damping pass
@@ -342,25 +350,25 @@ __device__ __forceinline__ void rhs_tight(double w, double xr, double Rh, double
   }
 }
 
-template <bool DAMP>
+template <bool DAMP, int T>
 __device__ __forceinline__ double rk4_tight(State &s, double vl0, double vlm, double vl1, const Lane &L, const Consts &K, Guard &g) {
   double a0, a1, a2, b0, b1, b2, c0, c1, c2, e0, e1, e2, w, q;
   const double Rh = s.rx;
   rhs_tight<DAMP>(s.w, L.hhd, Rh, vl0, L.bh, L, K, a0, a1, a2);
   double sv = s.w * a2;  // k1 + k4 of dV/dt (in units of vk), and k2 + k3 below: 5 instructions for the weighted sum
-  tight_incr<true>(a1, L.khh * a0, L, s.w, w, q, g);
+  tight_incr<T, true>(a1, L.khh * a0, L, s.w, w, q, g);
   rhs_tight<DAMP>(w, __builtin_fma(L.hhd, a1, L.hhd), Rh, vlm, __builtin_fma(L.bh, q, L.bh), L, K, b0, b1, b2);
   double sm = w * b2;
-  tight_incr<true>(b1, L.khh * b0, L, s.w, w, q, g);
+  tight_incr<T, true>(b1, L.khh * b0, L, s.w, w, q, g);
   rhs_tight<DAMP>(w, __builtin_fma(L.hhd, b1, L.hhd), Rh, vlm, __builtin_fma(L.bh, q, L.bh), L, K, c0, c1, c2);
   sm = __builtin_fma(w, c2, sm);
-  tight_incr<false>(c1 + c1, L.kh * c0, L, s.w, w, q, g);
+  tight_incr<T, false>(c1 + c1, L.kh * c0, L, s.w, w, q, g);
   rhs_tight<DAMP>(w, __builtin_fma(L.hd, c1, L.hhd), Rh, vl1, __builtin_fma(L.bh, q, L.bh), L, K, e0, e1, e2);
   sv = __builtin_fma(w, e2, sv);
   const double t0 = a0 + 2.0 * b0 + 2.0 * c0 + e0;
   const double t1 = a1 + 2.0 * b1 + 2.0 * c1 + e1;
   const double rho = t1 * (1.0 / 3.0);  // (h/6Dc)/x times the unscaled sum
-  tight_incr<false>(rho, L.kh6 * t0, L, s.w, w, q, g);
+  tight_incr<T, false>(rho, L.kh6 * t0, L, s.w, w, q, g);
   s.ms = __builtin_fma(K.h6, t0, s.ms);
   s.w = w;
   s.rx = __builtin_fma(Rh, q, Rh);  // x' = x (1 + rho), exact to rounding for |rho| < 2^-20; like w, resynced
@@ -401,8 +409,8 @@ __device__ __forceinline__ double rk4_wider(State &s, double vl0, double vlm, do
 template <bool DAMP, int T>
 __device__ __forceinline__ double rk4_fast(State &s, double vl0, double vlm, double vl1, const Lane &L,
                                            const Consts &K, Guard &g) {
-  if constexpr (T == TIGHT) return rk4_tight<DAMP>(s, vl0, vlm, vl1, L, K, g);
-  else return rk4_wider<DAMP, T>(s, vl0, vlm, vl1, L, K, g);
+  if constexpr (T == WIDE) return rk4_wider<DAMP, T>(s, vl0, vlm, vl1, L, K, g);
+  else return rk4_tight<DAMP, T>(s, vl0, vlm, vl1, L, K, g);
 }
 
 __device__ __forceinline__ State initial_state(double dc, const Lane &L, const Consts &K) {
@@ -542,7 +550,7 @@ __device__ __forceinline__ int integrate_pairs(const double *lds, const double *
 // A tripped guard redoes the trip with full evaluations; TIGHT and NARROW then hand the rest of the chunk to the next
 // wider tier (`tripped`), like integrate_pairs, which takes whatever remainder (< NU steps) is left.
 constexpr int kTightUnroll = 8;  // steps per trip of the TIGHT loop (the one-parameter sampler runs 2 * kTightUnroll, rsf_kernels.h)
-constexpr int kWiderUnroll = 4;  // NARROW and WIDE
+constexpr int kNarrowUnroll = 8, kWiderUnroll = 4;  // NARROW; WIDE
 template <bool DAMP, bool WANT_SSQ, bool WANT_ACC, int T, bool S1, int NU>
 __device__ __forceinline__ int integrate_multi(const double *lds, const double *ld, const Consts &K, Lane L, int k0, int kn, int r,
                                                int nsteps, State &s, Emit &em, double &ssq, double *acc_out, int64_t stride,
@@ -592,11 +600,12 @@ __device__ __forceinline__ int integrate_multi(const double *lds, const double *
 }
 
 // Wave-uniform choice of the starting tier — a speed decision only: every tier is exact to rounding inside its guard, and
-// a tier whose guard trips redoes that trip in full and hands over to the next wider one.  TIGHT is tried whenever the
-// mu increment allows it (|V_l - v| <~ 1.2 V_ref): theta tracks its steady state closely (|dtheta/theta| ~ 1e-7 per
-// stage at Dc ~ 1000, h = 0.1), which no a-priori bound captures.
+// a tier whose guard trips redoes that trip in full and hands over to the next wider one.  TIGHT and NARROW are tried whenever
+// the mu increment allows it (|V_l - v| <~ 1.2 V_ref against their |dlt| guards 2^-9 / 2^-7): theta tracks its steady state
+// closely (|dtheta/theta| ~ 1e-7 per stage at Dc ~ 1000, h = 0.1), which no a-priori bound captures.
 __device__ __forceinline__ int start_tier(const Lane &L, const Consts &K) {
-  return !__any(!(1.2 * K.V_ref * K.h * L.kia < 0x1.0p-9)) ? TIGHT : (!__any(!(4.0 * K.h * L.vdc < 0x1.0p-9)) ? NARROW : WIDE);
+  const double dk = 1.2 * K.V_ref * K.h * L.kia;
+  return !__any(!(dk < 0x1.0p-9)) ? TIGHT : (!__any(!(dk < 0x1.0p-7)) ? NARROW : WIDE);
 }
 
 template <bool DAMP, bool WANT_SSQ, bool WANT_ACC, bool S1, int NUT>
@@ -615,9 +624,11 @@ __device__ __forceinline__ void integrate_tiers(const double *lds, const double 
     if (!t_trip) r = integrate_pairs<DAMP, WANT_SSQ, WANT_ACC, TIGHT, S1>(lds, ld, K, L, k0, r, nsteps, s, em, ssq, acc_out, stride);
     tier_leave<TIGHT>(s, L);
   }
-  if (tier <= NARROW) {
-    r = integrate_multi<DAMP, WANT_SSQ, WANT_ACC, NARROW, S1, kWiderUnroll>(lds, ld, K, L, k0, kn, r, nsteps, s, em, ssq, acc_out, stride, n_trip);
+  if (tier <= NARROW && r < nsteps) {
+    tier_enter<NARROW>(s, L);
+    r = integrate_multi<DAMP, WANT_SSQ, WANT_ACC, NARROW, S1, kNarrowUnroll>(lds, ld, K, L, k0, kn, r, nsteps, s, em, ssq, acc_out, stride, n_trip);
     if (!n_trip) r = integrate_pairs<DAMP, WANT_SSQ, WANT_ACC, NARROW, S1>(lds, ld, K, L, k0, r, nsteps, s, em, ssq, acc_out, stride);
+    tier_leave<NARROW>(s, L);
   }
   r = integrate_multi<DAMP, WANT_SSQ, WANT_ACC, WIDE, S1, kWiderUnroll>(lds, ld, K, L, k0, kn, r, nsteps, s, em, ssq, acc_out, stride, unused);
   r = integrate_pairs<DAMP, WANT_SSQ, WANT_ACC, WIDE, S1>(lds, ld, K, L, k0, r, nsteps, s, em, ssq, acc_out, stride);
