@@ -66,9 +66,8 @@ struct Lane {
   double tc;      // -mu_ref/a
   double hhd, hd, h6d;  // (h/2)/Dc, h/Dc, (h/6)/Dc : theta increments in x units
   double inv_hhd, bh;   // 1/hhd and beta/hhd: the TIGHT tier carries hhd/x in place of 1/x (rk4_tight)
-  double c_l1p;   // leading series coefficients of the active tier, kept in VGPRs (a VOP3 takes one SGPR source and
-  double c_em1;   //   the first Horner term has two non-inline constants); see set_tier
-  double c_em1h;  // TIGHT: 1/24, the leading coefficient of its expm1 series
+  double c_l1p, c_l1q;  // series coefficients of the active tier kept in VGPRs (a VOP3 takes one SGPR source and the first Horner
+  double c_em1;         //   term has two non-inline constants), see set_tier: b/3a and -b/4a of log1p, expm1's leading coefficient
 };
 
 template <int T>
@@ -134,28 +133,6 @@ __device__ __forceinline__ void rhs_tail(double w, double rx, double x, double v
   d2 = w * g;
 }
 
-// The same RHS arranged for the hot loop, with the caller supplying brx = beta/x at the stage point: the bracket of
-// dV/dt = vk w g is  g = d0 - (beta/x) d1  — one fma on the two derivatives the stage forms anyway.  Working on g rather
-// than on vk g makes the damping pass ONE product shared by both corrections: d0 -= (kvk w) g and g -= (kvk w) g.
-// The caller forms w g (the stage's dV/dt in units of vk) inside its weighted sum.
-// (Rounds 1-2 wrote g = (V_l - beta/x) + (beta - V_ref) w, linear in w, so that all but one fma was ready before w — the
-// end of the previous stage's dependency chain — arrived: one instruction more per stage for one dependent level less.
-// Measured in round 3 (profiles/r03/ab_gform.log) the shorter instruction stream wins at every shape, also at cfg1's one
-// wave per SIMD: +2.1 % cfg1, +3.0 % cfg2, +2.5 % d = 3.  The rounding is the same: d1 = 1 - w x comes out of one fma with
-// an absolute error of 1e-16, which beta/x ~ 0.14 scales to 2e-17 of g.)
-template <bool DAMP>
-__device__ __forceinline__ void rhs_fast(double w, double x, double vl, double brx, const Lane &L, const Consts &K, double &d0,
-                                         double &d1, double &g) {
-  d1 = __builtin_fma(-w, x, 1.0);
-  d0 = __builtin_fma(-K.V_ref, w, vl);
-  g = __builtin_fma(-brx, d1, d0);
-  if (DAMP) {
-    const double kw = L.kvk * w;
-    d0 = __builtin_fma(-kw, g, d0);
-    g = __builtin_fma(-kw, g, g);
-  }
-}
-
 // (w, 1/x) by full evaluation
 __device__ __forceinline__ void eval_full(double ms, double x, const Lane &L, const Consts &K, double &w, double &rx) {
   w = fm::exp(__builtin_fma(-L.boa, fm::log(x), __builtin_fma(ms, L.kia, L.tc)));
@@ -166,13 +143,13 @@ enum Tier : int { TIGHT = 0, NARROW = 1, WIDE = 2 };
 
 // the TIGHT and NARROW tiers' representation of 1/x (struct State)
 template <int T>
-__device__ __forceinline__ void tier_enter(State &s, const Lane &L) { if (T != WIDE) s.rx *= L.hhd; }
+__device__ __forceinline__ void tier_enter(State &s, const Lane &L) { s.rx *= L.hhd; }
 template <int T>
-__device__ __forceinline__ void tier_x(State &s, const Lane &L) { if (T != WIDE) s.x = L.hhd * fm::rcp(s.rx); }  // x from Rh
+__device__ __forceinline__ void tier_x(State &s, const Lane &L) { s.x = L.hhd * fm::rcp(s.rx); }  // x from Rh
 template <int T>
 __device__ __forceinline__ void tier_leave(State &s, const Lane &L) {
   tier_x<T>(s, L);
-  if (T != WIDE) s.rx *= L.inv_hhd;
+  s.rx *= L.inv_hhd;
 }
 template <int T>
 __device__ __forceinline__ void eval_full_t(State &s, const Lane &L, const Consts &K) {  // from (ms, x)
@@ -214,53 +191,23 @@ constexpr float hi_pow2(int e) { return __builtin_bit_cast(float, (1023 + e) << 
 // leading series coefficients of a tier (kept in VGPRs, see Lane)
 template <int T>
 __device__ __forceinline__ void set_tier(Lane &L) {
-  // TIGHT: log1p needs none (rho (b/a - (b/2a) rho), Lane::nhboa), expm1 leads with 1/24;  NARROW: (b/3a) rho^2 more and 1/720;
-  // WIDE: the unscaled series of eval_incr
-  L.c_l1p = T == NARROW ? L.boa * (1.0 / 3.0) : 1.0 / 7.0;
-  L.c_em1 = T == NARROW ? 1.0 / 720.0 : 1.0 / 5040.0;
-  L.c_em1h = 1.0 / 24.0;
-  asm volatile("" : "+v"(L.c_l1p), "+v"(L.c_em1), "+v"(L.c_em1h));  // opaque: stays a register value, not re-materialised per step
-}
-
-// the WIDE tier's form (TIGHT and NARROW work on scaled derivatives: tight_incr)
-template <int T>
-__device__ __forceinline__ void eval_incr(double kf, double dms_dt, double R, double dth_dt, double x1, const Lane &L, double w0,
-                                          double rx0, double &w, double &rx, Guard &g) {
-  static_assert(T == WIDE, "");
-  // dk = kf * dms_dt (kf: kia times the step fraction);  rho = R * dth_dt (R: step fraction / Dc / x, once per step)
-  const double rho = dth_dt * R;
-  g.rho = __builtin_fmaxf(g.rho, __builtin_fabsf(hi_as_float(rho)));
-  double p = fm::hfma(L.c_l1p, rho, -1.0 / 6.0);
-  p = fm::hfma(p, rho, 1.0 / 5.0);
-  p = fm::hfma(p, rho, -1.0 / 4.0);
-  p = fm::hfma(p, rho, 1.0 / 3.0);
-  p = __builtin_fma(p, rho, -0.5);
-  p = __builtin_fma(p, rho, 1.0);
-  const double dlt = __builtin_fma(-(L.boa * rho), p, kf * dms_dt);  // d1 -> rho -> p -> dlt: three deep
-  g.dlt = __builtin_fmaxf(g.dlt, __builtin_fabsf(hi_as_float(dlt)));
-  double e = fm::hfma(L.c_em1, dlt, 1.0 / 720.0);
-  e = fm::hfma(e, dlt, 1.0 / 120.0);
-  e = fm::hfma(e, dlt, 1.0 / 24.0);
-  e = fm::hfma(e, dlt, 1.0 / 6.0);
-  e = __builtin_fma(e, dlt, 0.5);
-  e = __builtin_fma(e, dlt, 1.0);
-  w = __builtin_fma(w0 * dlt, e, w0);  // w0*dlt is off the critical path (e is the late operand)
-  rx = __builtin_fma(-rho, rx0, rx0);
-  rx = __builtin_fma(rx, __builtin_fma(-x1, rx, 1.0), rx);
-  rx = __builtin_fma(rx, __builtin_fma(-x1, rx, 1.0), rx);
+  L.c_l1p = L.boa * (1.0 / 3.0);                                             // (TIGHT needs neither: Lane::nhboa)
+  L.c_l1q = L.boa * (-1.0 / 4.0);                                            // (WIDE only)
+  L.c_em1 = T == TIGHT ? 1.0 / 24.0 : (T == NARROW ? 1.0 / 720.0 : 1.0 / 40320.0);
+  asm volatile("" : "+v"(L.c_l1p), "+v"(L.c_l1q), "+v"(L.c_em1));  // opaque: stays a register value, not re-materialised per step
 }
 
 template <int T>
 __device__ __forceinline__ bool guard_ok(const Guard &g) {  // NaN passes through (see Guard)
-  return (g.rho < (T == WIDE ? hi_pow2(-7) : (T == NARROW ? hi_pow2(-14) : hi_pow2(-20)))) &&
-         (g.dlt < (T == TIGHT ? hi_pow2(-9) : (T == NARROW ? hi_pow2(-7) : hi_pow2(-6)))) && (T != TIGHT || g.dlt_h < hi_pow2(-10));
+  return (g.rho < (T == WIDE ? hi_pow2(-11) : (T == NARROW ? hi_pow2(-14) : hi_pow2(-20)))) &&
+         (g.dlt < (T == TIGHT ? hi_pow2(-9) : (T == NARROW ? hi_pow2(-7) : hi_pow2(-5)))) && (T != TIGHT || g.dlt_h < hi_pow2(-10));
 }
 
 // ---------------------------------------------------------------------------------------------
 // One classical RK4 step of size h; vl0/vlm/vl1 = V_l at t, t+h/2, t+h.
 //
 // Hot path (rk4_fast): the state carries (w, 1/th) at its own point, so stage 1 needs no
-// transcendental at all; stages 2-4 and the step's end point are reached by eval_incr from the
+// transcendental at all; stages 2-4 and the step's end point are reached by tight_incr from the
 // step's start point.  Straight-line code on purpose: with one wave per SIMD (cfg1) every
 // instruction, nop and branch costs a full ~5-cycle issue slot (tools/microbench_fp64.hip).
 // The largest increments of a PAIR of steps are checked once (integrate_pairs); if a lane left the tier's
@@ -273,7 +220,7 @@ constexpr int kResync = 512;  // power of two; every trip length below divides i
                               // state arrives there from a full evaluation or from the previous chunk's steps, never stale.
 
 // Both step functions return the weighted sum of the V derivatives, k1 + 2 k2 + 2 k3 + k4, IN UNITS OF vk (rhs_tail /
-// rhs_fast): the velocity increment of the step is (h/6) vk = L.h6v times it.  V itself never feeds back into the RHS, so the hot loop does not carry it: with one
+// rhs_tight): the velocity increment of the step is (h/6) vk = L.h6v times it.  V itself never feeds back into the RHS, so the hot loop does not carry it: with one
 // step per output sample the acceleration (V_k - V_{k-1})/delta_t (RateStateModel.py:388) IS cacc * sum.
 template <bool DAMP>
 __device__ __forceinline__ double rk4_cold(State &s, double vl0, double vlm, double vl1, const Lane &L,
@@ -308,35 +255,46 @@ __device__ __forceinline__ double rk4_cold(State &s, double vl0, double vlm, dou
 // fewer than the unscaled form.  x itself is not carried at all: Rh IS the state (x = hhd / Rh where a full evaluation
 // needs it), updated once per step, so Rh x_0 = hhd holds by construction.
 //
-// The NARROW tier is the same step with one more term in each series — log1p to rho^3/3, expm1 to dlt^6/720,
-// 1/x' = (1/x)(1 - rho + rho^2 - rho^3) — which carries it to |rho| < 2^-14, |dlt| < 2^-7 (truncations 4.5e-18, 4.5e-17, 1.4e-17):
-// four instructions more per evaluation.  (Until round 3 it was the unscaled form with Newton steps on 1/x that the WIDE
-// tier still uses: 131 instructions per step against 101, and its a-priori bound reached less far down in Dc.)
+// The wider tiers are the same step with longer series: NARROW one more term each — log1p to rho^3/3, expm1 to dlt^6/720,
+// 1/x' = (1/x)(1 - rho + rho^2 - rho^3): |rho| < 2^-14, |dlt| < 2^-7 (truncations 4.5e-18, 4.5e-17, 1.4e-17), four
+// instructions more per evaluation — and WIDE one and two more again — rho^4/4, dlt^8/40320, ... + rho^4: |rho| < 2^-11,
+// |dlt| < 2^-5 (7e-18, 2.4e-18, 2.8e-17).  (Until round 3 they were an unscaled form with Newton steps on 1/x: 131 and 144
+// instructions per step against 102 and 118, and their a-priori bounds reached less far down in Dc.)
 template <int T, bool HALF>
 __device__ __forceinline__ void tight_incr(double rho, double dk, const Lane &L, double w0, double &w, double &q, Guard &g) {
-  static_assert(T == TIGHT || T == NARROW, "");
   g.rho = __builtin_fmaxf(g.rho, __builtin_fabsf(hi_as_float(rho)));
-  double pb = T == NARROW ? __builtin_fma(rho, L.c_l1p, L.nhboa) : L.nhboa;  // (b/a)(1 - rho/2 [+ rho^2/3])
+  double pb = L.nhboa;  // (b/a)(1 - rho/2 [+ rho^2/3 [- rho^3/4]])
+  if (T == NARROW) pb = __builtin_fma(rho, L.c_l1p, pb);
+  if (T == WIDE) pb = __builtin_fma(rho, __builtin_fma(rho, L.c_l1q, L.c_l1p), pb);
   const double dlt = __builtin_fma(-rho, __builtin_fma(rho, pb, L.boa), dk);
   // TIGHT: expm1 to dlt^4/24 at every stage, half-step stages held to |dlt| < 2^-10, the others to 2^-9
   if (T == TIGHT && HALF) g.dlt_h = __builtin_fmaxf(g.dlt_h, __builtin_fabsf(hi_as_float(dlt)));
   else g.dlt = __builtin_fmaxf(g.dlt, __builtin_fabsf(hi_as_float(dlt)));
-  double e;
-  if (T == NARROW) {
-    e = fm::hfma(L.c_em1, dlt, 1.0 / 120.0);
-    e = fm::hfma(e, dlt, 1.0 / 24.0);
-    e = fm::hfma(e, dlt, 1.0 / 6.0);
-  } else {
-    e = fm::hfma(L.c_em1h, dlt, 1.0 / 6.0);
+  double e = L.c_em1;
+  if (T == WIDE) {
+    e = fm::hfma(e, dlt, 1.0 / 5040.0);
+    e = fm::hfma(e, dlt, 1.0 / 720.0);
   }
+  if (T != TIGHT) {
+    e = fm::hfma(e, dlt, 1.0 / 120.0);
+    e = fm::hfma(e, dlt, 1.0 / 24.0);
+  }
+  e = fm::hfma(e, dlt, 1.0 / 6.0);
   e = __builtin_fma(e, dlt, 0.5);
   e = __builtin_fma(e, dlt, 1.0);
   w = __builtin_fma(w0 * dlt, e, w0);
   const double r1 = __builtin_fma(rho, rho, -rho);                 // -rho + rho^2
-  q = T == NARROW ? __builtin_fma(-rho, r1, -rho) : r1;             // 1/x' = (1/x)(1 + q);  NARROW: -rho + rho^2 - rho^3
+  q = r1;                                                          // 1/x' = (1/x)(1 + q)
+  if (T != TIGHT) q = __builtin_fma(-rho, q, -rho);                // NARROW: -rho + rho^2 - rho^3
+  if (T == WIDE) q = __builtin_fma(-rho, q, -rho);                 // WIDE: ... + rho^4
 }
 
-// d0 = V_l - V_ref w,  d1' = Rh - w xr  (xr = Rh x at the stage),  g = d0 - brx d1'  (brx = bh (1 + q)) and the damping pass
+// d0 = V_l - V_ref w,  d1' = Rh - w xr  (xr = Rh x at the stage),  g = d0 - brx d1'  (brx = bh (1 + q)) and the damping pass.
+// g is the bracket of dV/dt = vk w g, one fma on the two derivatives the stage forms anyway; working on g rather than on
+// vk g makes the damping pass ONE product shared by both corrections: d0 -= (kvk w) g and g -= (kvk w) g; the caller forms
+// w g (the stage's dV/dt in units of vk) inside its weighted sum.  (Rounds 1-2 wrote g linear in w so that all but one fma
+// was ready before w — the end of the previous stage's dependency chain — arrived: one instruction more per stage for one
+// dependent level less; measured in round 3, profiles/r03/ab_gform.log, the shorter stream wins at every shape.)
 template <bool DAMP>
 __device__ __forceinline__ void rhs_tight(double w, double xr, double Rh, double vl, double brx, const Lane &L, const Consts &K,
                                           double &d0, double &d1, double &g) {
@@ -376,41 +334,9 @@ __device__ __forceinline__ double rk4_tight(State &s, double vl0, double vlm, do
 }
 
 template <bool DAMP, int T>
-__device__ __forceinline__ double rk4_wider(State &s, double vl0, double vlm, double vl1, const Lane &L,
-                                            const Consts &K, Guard &g) {
-  double a0, a1, a2, b0, b1, b2, c0, c1, c2, e0, e1, e2, w, rx, xs;
-  // rho of a stage = its theta derivative times Rh / Rf / R6
-  const double Rh = L.hhd * s.rx, Rf = Rh + Rh, R6 = L.h6d * s.rx;
-  rhs_fast<DAMP>(s.w, s.x, vl0, L.beta * s.rx, L, K, a0, a1, a2);
-  double sv = s.w * a2;  // k1 + k4 of dV/dt (in units of vk), and k2 + k3 below: 5 instructions for the weighted sum
-  xs = __builtin_fma(L.hhd, a1, s.x);
-  eval_incr<T>(L.khh, a0, Rh, a1, xs, L, s.w, s.rx, w, rx, g);
-  rhs_fast<DAMP>(w, xs, vlm, L.beta * rx, L, K, b0, b1, b2);
-  double sm = w * b2;
-  xs = __builtin_fma(L.hhd, b1, s.x);
-  eval_incr<T>(L.khh, b0, Rh, b1, xs, L, s.w, s.rx, w, rx, g);
-  rhs_fast<DAMP>(w, xs, vlm, L.beta * rx, L, K, c0, c1, c2);
-  sm = __builtin_fma(w, c2, sm);
-  xs = __builtin_fma(L.hd, c1, s.x);
-  eval_incr<T>(L.kh, c0, Rf, c1, xs, L, s.w, s.rx, w, rx, g);
-  rhs_fast<DAMP>(w, xs, vl1, L.beta * rx, L, K, e0, e1, e2);
-  sv = __builtin_fma(w, e2, sv);
-  const double t0 = a0 + 2.0 * b0 + 2.0 * c0 + e0;
-  const double t1 = a1 + 2.0 * b1 + 2.0 * c1 + e1;
-  const double x1 = __builtin_fma(L.h6d, t1, s.x);
-  eval_incr<T>(L.kh6, t0, R6, t1, x1, L, s.w, s.rx, w, rx, g);
-  s.ms = __builtin_fma(K.h6, t0, s.ms);
-  s.x = x1;
-  s.w = w;
-  s.rx = rx;
-  return __builtin_fma(2.0, sm, sv);
-}
-
-template <bool DAMP, int T>
 __device__ __forceinline__ double rk4_fast(State &s, double vl0, double vlm, double vl1, const Lane &L,
                                            const Consts &K, Guard &g) {
-  if constexpr (T == WIDE) return rk4_wider<DAMP, T>(s, vl0, vlm, vl1, L, K, g);
-  else return rk4_tight<DAMP, T>(s, vl0, vlm, vl1, L, K, g);
+  return rk4_tight<DAMP, T>(s, vl0, vlm, vl1, L, K, g);
 }
 
 __device__ __forceinline__ State initial_state(double dc, const Lane &L, const Consts &K) {
@@ -630,6 +556,8 @@ __device__ __forceinline__ void integrate_tiers(const double *lds, const double 
     if (!n_trip) r = integrate_pairs<DAMP, WANT_SSQ, WANT_ACC, NARROW, S1>(lds, ld, K, L, k0, r, nsteps, s, em, ssq, acc_out, stride);
     tier_leave<NARROW>(s, L);
   }
+  if (r >= nsteps) return;
+  tier_enter<WIDE>(s, L);
   r = integrate_multi<DAMP, WANT_SSQ, WANT_ACC, WIDE, S1, kWiderUnroll>(lds, ld, K, L, k0, kn, r, nsteps, s, em, ssq, acc_out, stride, unused);
   r = integrate_pairs<DAMP, WANT_SSQ, WANT_ACC, WIDE, S1>(lds, ld, K, L, k0, r, nsteps, s, em, ssq, acc_out, stride);
   if (r < nsteps) {  // odd last step of the chunk (it always completes a sample): one WIDE step, cold if its guard trips
@@ -643,12 +571,15 @@ __device__ __forceinline__ void integrate_tiers(const double *lds, const double 
       s = save;
       trip_cold<DAMP, WIDE, 1>(v, L, K, s, dv);
     }
+    tier_leave<WIDE>(s, L);
     if (S1) {
       emit_incr<WANT_SSQ, WANT_ACC>(dv[0], kn - 1, obs, L, k0, ssq, acc_out, stride);
     } else {
       s.V = __builtin_fma(L.h6v, dv[0], s.V);
       emit_at<WANT_SSQ, WANT_ACC>(s.V, em.vprev, kn - 1, obs, K, k0, ssq, acc_out, stride);
     }
+  } else {
+    tier_leave<WIDE>(s, L);
   }
 }
 

@@ -155,7 +155,7 @@ struct GuardD {
 //     (h/theta_0) theta_s/Dc = (h/Dc)(1 + rho),      (h/a) k'(V_l - v) = hk (V_l - v),  hk = (h/a) k',
 //     (h/a)(b/theta_s) dtheta/dt = (b/a)(1 + q) kt',  q = rho^2 - rho        (b/theta_s = (b/theta_0)(1 + q)),
 // the bracket of dV/dt = (v/a)(dmu/dt - (b/theta) dtheta/dt) being one fma on the two derivatives the stage forms anyway
-// (rsf_device.h's rhs_fast); the damping pass (RateStateModel.py:349-353) subtracts the same k1 kv' from km' and from the
+// (rsf_device.h's rhs_tight); the damping pass (RateStateModel.py:349-353) subtracts the same k1 kv' from km' and from the
 // bracket.  The closing sums undo the scaling with a, theta_0, a in place of h (closing_fast).  21 operations per stage.
 struct FastStep {
   double ha, hr, hd, hk;   // h/a, h/theta_0, h/Dc, (h/a) k'

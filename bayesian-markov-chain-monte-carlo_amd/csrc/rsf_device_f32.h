@@ -9,7 +9,7 @@
 // the constants are pre-scaled for base 2.  The acceleration sample is formed from the step's
 // velocity INCREMENT, not from the difference of two velocities near V_ref, which would lose
 // ~4 digits in float32.  Same rescaled state as the float64 path — ms = mu/k', x = V_ref theta/Dc — and the same
-// regrouping of the RHS around w = v/V_ref with dV/dt in units of vk (rsf_device.h, rhs_fast); the two state components
+// regrouping of the RHS around w = v/V_ref with dV/dt in units of vk (rsf_device.h, rhs_tight); the two state components
 // and their derivatives are carried as packed pairs (v_pk_fma_f32).
 #pragma once
 #include <hip/hip_runtime.h>
@@ -57,7 +57,7 @@ __device__ __forceinline__ Lane32 make_lane32(double dc, double a, double b, con
   return L;
 }
 
-// The RHS at (ms, x) = s, RateStateModel.py:318-355 in the float64 path's regrouping (rsf_device.h, rhs_fast): with
+// The RHS at (ms, x) = s, RateStateModel.py:318-355 in the float64 path's regrouping (rsf_device.h, rhs_tight): with
 // w = v/V_ref = 2^(kia2 ms + tc2 - (b/a) log2 x) the bracket of dV/dt = vk w g is linear in w,
 //     g = (V_l - beta/x) + (beta - V_ref) w,
 // and the damping pass (RateStateModel.py:349-353) subtracts the same (kvk w) g from d(ms)/dt and from g.

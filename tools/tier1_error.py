@@ -40,8 +40,9 @@ def main():
             h = 50.0 / n
             edge = 1.2 * h * 0.1 / 0.011 * 512.0  # Dc at the TIGHT tier's a-priori bound (a = 0.011); NARROW's is a quarter of it
             dcn = np.sort(np.exp(rng.uniform(np.log(0.3 * edge), np.log(0.9 * edge), C)))  # "narrow": every wave on the NARROW tier
+            dcw = np.sort(np.exp(rng.uniform(np.log(0.07 * edge), np.log(0.22 * edge), C)))  # "wide": below NARROW's bound (edge / 4)
             for tag, kw, dcs in (("dc_only", {}, dc), ("dc_a_b", dict(a=a, b=b), dc), ("tight_dc_only", {}, dct),
-                                 ("tight_dc_a_b", dict(a=a, b=b), dct), ("narrow_dc_only", {}, dcn)):
+                                 ("tight_dc_a_b", dict(a=a, b=b), dct), ("narrow_dc_only", {}, dcn), ("wide_dc_only", {}, dcw)):
                 sg, ag = g.forward(dcs, data=data, want_ssq=True, want_acc=True, **kw)
                 sc, ac = c.forward(dcs, data=data, want_ssq=True, want_acc=True, **kw)
                 traj = np.abs(ag - ac).max(axis=0) / np.abs(ac).max(axis=0)
