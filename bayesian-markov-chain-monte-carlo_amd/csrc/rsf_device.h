@@ -2,7 +2,7 @@
 //
 //   Philox4x32-10 counter RNG + Box-Muller normals + Marsaglia-Tsang gamma   (K3)
 //   rate-and-state friction RHS and the classical RK4 step, per lane          (K1 core)
-//     hot path: 8-16 steps per loop trip, transcendentals carried incrementally (rk4_fast / integrate_multi; the
+//     hot path: 8-16 steps per loop trip, transcendentals carried incrementally (rk4_tight / integrate_multi; the
 //               remainder in pairs, integrate_pairs)
 //     cold path: full log/exp evaluation (rk4_cold), taken when an increment leaves the series' guard region
 //   cooperative LDS staging of the chain-independent tables (loading V_l(t), observation)
@@ -206,7 +206,7 @@ __device__ __forceinline__ bool guard_ok(const Guard &g) {  // NaN passes throug
 // ---------------------------------------------------------------------------------------------
 // One classical RK4 step of size h; vl0/vlm/vl1 = V_l at t, t+h/2, t+h.
 //
-// Hot path (rk4_fast): the state carries (w, 1/th) at its own point, so stage 1 needs no
+// Hot path (rk4_tight): the state carries (w, 1/th) at its own point, so stage 1 needs no
 // transcendental at all; stages 2-4 and the step's end point are reached by tight_incr from the
 // step's start point.  Straight-line code on purpose: with one wave per SIMD (cfg1) every
 // instruction, nop and branch costs a full ~5-cycle issue slot (tools/microbench_fp64.hip).
@@ -333,12 +333,6 @@ __device__ __forceinline__ double rk4_tight(State &s, double vl0, double vlm, do
   return __builtin_fma(2.0, sm, sv);
 }
 
-template <bool DAMP, int T>
-__device__ __forceinline__ double rk4_fast(State &s, double vl0, double vlm, double vl1, const Lane &L,
-                                           const Consts &K, Guard &g) {
-  return rk4_tight<DAMP, T>(s, vl0, vlm, vl1, L, K, g);
-}
-
 __device__ __forceinline__ State initial_state(double dc, const Lane &L, const Consts &K) {
   State s;
   s.ms = (K.mu0 * dc) * (1.0 / (1e-2 * 10));  // mu(0)/k' = mu_t_zero/k', RateStateModel.py:367-377
@@ -418,7 +412,7 @@ template <bool DAMP, int T, int NU>
 __device__ __forceinline__ bool trip_fast(const double *v, const Lane &L, const Consts &K, State &s, double (&dv)[NU]) {
   Guard g = {0, 0, 0};
 #pragma unroll
-  for (int j = 0; j < NU; ++j) dv[j] = rk4_fast<DAMP, T>(s, v[2 * j], v[2 * j + 1], v[2 * j + 2], L, K, g);
+  for (int j = 0; j < NU; ++j) dv[j] = rk4_tight<DAMP, T>(s, v[2 * j], v[2 * j + 1], v[2 * j + 2], L, K, g);
   return !guard_ok<T>(g);
 }
 
