@@ -12,16 +12,22 @@ accept/reject, inverse-gamma σ² update, adaptation — executes in the fused H
 RateStateModel.py:392), so `np.random.seed(s)` selects the same chain the reference would run.
 `sample_batched()` (additive) runs many independent chains per launch with the on-device
 Philox stream and is the throughput path.
+
+The model contract is the reference's (MCMC.py:65-66, 127, 381-384): ANY object with a settable `.Dc`
+and `.evaluate()` whose second element is the clean series.  This package's RateStateModel is integrated
+on the device inside the fused kernel; for any other model the host calls `model.evaluate()` where the
+reference would and the device runs the chain step on the sum of squares it is handed
+(rsf_mcmc_init_state / rsf_mcmc_propose / rsf_mcmc_replay_ssq).
 """
 import numpy as np
 
 if __package__:
     from . import _figures
-    from ._abi import ADAPT_MODES, RsfError
+    from ._abi import ADAPT_MODES, ERR_NOT_POSDEF, RsfError
     from .engine import Engine
 else:  # flat layout: this directory on sys.path, the reference's own import style (main.py:44-46)
     import _figures
-    from _abi import ADAPT_MODES, RsfError
+    from _abi import ADAPT_MODES, ERR_NOT_POSDEF, RsfError
     from engine import Engine
 
 
@@ -60,14 +66,20 @@ class MCMC:
         self.replay_reference_rng = True
 
     # ---- helpers ------------------------------------------------------------------------
+    def _device_model(self):
+        """True: the model is this package's RateStateModel, integrated on the device inside the sampler kernel.
+        False: any other object with `.Dc` and `.evaluate()` — the host evaluates it, the device runs the chain step."""
+        return hasattr(self.model, "engine")
+
     def _engine(self):
         if self.lstm_model:
             raise NotImplementedError("the reduced-order-model hook (MCMC.py:124-125) has no implementation "
                                       "in the reference either; pass a falsy lstm_model")
-        if not hasattr(self.model, "engine"):
-            raise TypeError("the HIP path integrates the rate-and-state model itself: `model` must be this "
-                            "package's RateStateModel (duck-typed Python models cannot run on the GPU)")
-        return self.model.engine()
+        if self._device_model():
+            return self.model.engine()
+        if getattr(self, "_host_engine", None) is None:
+            self._host_engine = Engine(mem="host")  # no set_model: the chain logic alone (rsf_mcmc_init_state)
+        return self._host_engine
 
     def _prior_is_dict(self):
         return hasattr(self.qpriors, "keys")
@@ -94,24 +106,41 @@ class MCMC:
         return self.model.evaluate()[1]
 
     def SSqcalc(self, q_new):
-        """Sum of squares at q_new (d, 1) → (1, 1) (MCMC.py:381-387); one GPU forward solve."""
-        eng = self._engine()
+        """Sum of squares at q_new (d, 1) → (1, 1) (MCMC.py:381-387); one GPU forward solve — or, for a model that is not
+        this package's RateStateModel, one `model.evaluate()` on the host."""
         self.model.Dc = q_new[0, ]
+        if not self._device_model():
+            acc = np.asarray(self.evaluate_model(), dtype=np.float64)
+            return np.sum((acc.reshape(1, -1) - np.asarray(self.data, dtype=np.float64).reshape(1, -1)) ** 2, axis=1, keepdims=True)
+        eng = self._engine()
         dc = float(np.asarray(self.model.Dc, dtype=np.float64).reshape(-1)[0])
         ssq, _ = eng.forward([dc], data=np.asarray(self.data, dtype=np.float64).reshape(-1), want_ssq=True, want_acc=False)
         return ssq.reshape(1, 1)
 
+    def _chain_key(self):
+        # the chain on the engine belongs to THIS sampler and THIS observation: a different `data` array means new chains
+        return (id(self), id(self.data), len(self.data))
+
     def _scratch_chain(self, eng):
         """The engine's one-chain sampler state the sub-methods work on (created by compute_initial_covariance, or here)."""
-        if eng.n_chains != 1 or eng.n_params != 1 or getattr(eng, "_chain_owner", None) is not self:
-            self._init_chains(eng, np.array([[float(self.qstart)]]))
-            eng._chain_owner = self
+        if eng.n_chains != 1 or eng.n_params != 1 or getattr(eng, "_chain_owner", None) != self._chain_key():
+            if self._device_model():
+                self._init_chains(eng, np.array([[float(self.qstart)]]))
+            else:  # any state will do: every sub-method sets the state it works from
+                eng.mcmc_init_state([[float(self.qstart)]], [0.0], [1.0], [[[0.0]]], self.qstart_limits[:, 0], self.qstart_limits[:, 1],
+                                    n0=self.n0, prior_len=len(self.qpriors), adapt_mode=self._adapt_mode(),
+                                    adapt_interval=self.adapt_interval)
+            eng._chain_owner = self._chain_key()
         return eng
 
-    def _one_iteration(self, eng, q, ssq, std2, V, z, u, g):
-        """One kernel iteration (rsf_mcmc_replay) from an explicit chain state → (q, SSq, sigma^2, accepted) after it."""
+    def _one_iteration(self, eng, q, ssq, std2, V, z, u, g, ssq_new=None):
+        """One kernel iteration from an explicit chain state → (q, SSq, sigma^2, accepted) after it.  rsf_mcmc_replay (the
+        kernel solves the proposal itself), or rsf_mcmc_replay_ssq when the host has evaluated the model (ssq_new)."""
         eng.set_state(q=[[q]], ssq=[ssq], std2=[std2], V=[[[V]]])
-        tq, ts, ta = eng.mcmc_replay(np.array([[[z]]]), np.array([[u]]), np.array([[g]]))
+        if ssq_new is None:
+            tq, ts, ta = eng.mcmc_replay(np.array([[[z]]]), np.array([[u]]), np.array([[g]]))
+        else:
+            tq, ts, ta = eng.mcmc_replay_ssq(np.array([[[z]]]), np.array([[u]]), np.array([[g]]), np.array([[ssq_new]]))
         return float(tq[0, 0, 0]), float(eng.get_state()[1][0]), float(ts[0, 0]), bool(ta[0, 0])
 
     def acceptreject(self, q_new, SSqprev, std2):
@@ -120,13 +149,17 @@ class MCMC:
         eng = self._scratch_chain(self._engine())
         q = float(np.asarray(q_new, dtype=np.float64).reshape(-1)[0])
         lo, hi = float(self.qstart_limits[0, 0]), float(self.qstart_limits[0, 1])
-        u = 1.0
+        u, ssq_new = 1.0, None
         if q > lo and q < hi:
-            if self.replay_reference_rng:
+            if not self._device_model():
+                ssq_new = float(self.SSqcalc(np.asarray(q_new, dtype=np.float64).reshape(-1, 1))[0, 0])  # the model draws what it draws
+            elif self.replay_reference_rng:
                 np.random.randn(len(self.data))  # the N normals the reference's forward solve wastes (RateStateModel.py:392)
             u = np.random.rand()
+        elif not self._device_model():
+            ssq_new = 0.0  # out of bounds: never read
         # proposal = q + chol(V) z with V = 0: the kernel proposes exactly q_new from the state (q_new, SSqprev, std2)
-        _, ssq, _, accept = self._one_iteration(eng, q, float(np.asarray(SSqprev).reshape(-1)[0]), float(std2), 0.0, 0.0, u, 1.0)
+        _, ssq, _, accept = self._one_iteration(eng, q, float(np.asarray(SSqprev).reshape(-1)[0]), float(std2), 0.0, 0.0, u, 1.0, ssq_new)
         return accept, (np.array([[ssq]]) if accept else SSqprev)
 
     def update_standard_deviation(self, SSqprev):
@@ -135,7 +168,7 @@ class MCMC:
         eng = self._scratch_chain(self._engine())
         g = np.random.standard_gamma(0.5 * (self.n0 + len(self.data)))  # == gamma.rvs(aval, scale=1/bval) * bval
         _, _, s2, _ = self._one_iteration(eng, float(self.qstart), float(np.asarray(SSqprev).reshape(-1)[0]), float(self.std2[-1]),
-                                          1.0, np.inf, 1.0, g)
+                                          1.0, np.inf, 1.0, g, None if self._device_model() else 0.0)
         self.std2.append(s2)
 
     def update_covariance_matrix(self, qparams):
@@ -143,32 +176,46 @@ class MCMC:
         prior has no .keys(): AttributeError, as in the reference (whose loop swallows it: the chain never adapts)."""
         n_keys = len(self.qpriors.keys())
         window = np.asarray(qparams, dtype=np.float64)[:, -self.adapt_interval:].T
+        if window.shape[1] != 1:
+            # the reference's np.cov / cholesky take any number of rows, but its sampler has ONE parameter (MCMC.py:98, 381) and
+            # so has this quirk mode on the device; say so instead of reporting a covariance failure the caller would swallow
+            raise NotImplementedError(f"update_covariance_matrix: qparams has {window.shape[1]} rows; the reference sampler and its "
+                                      "dict-prior adaptation are one-parameter (corrected adaptation for 3 parameters: "
+                                      "sample_batched(adapt_mode='am'))")
         try:
             return self._engine().mcmc_adapt(window, "reference_dict", prior_len=n_keys)
         except RsfError as ex:
-            if ex.code == -1:
+            if ex.code == ERR_NOT_POSDEF:  # only this status is np.linalg.cholesky's failure (MCMC.py:203, 524-527)
                 raise np.linalg.LinAlgError("Matrix is not positive definite") from ex
             raise
 
-    _vstart_override = None  # test hook: a value, or callable(mcmc) → value, that replaces the device's Vstart (tests/)
-
     def compute_initial_covariance(self):
-        """std2[0] and Vstart (MCMC.py:244-266) from the device init kernel."""
+        """std2[0] and Vstart (MCMC.py:244-266): from the device init kernel, or — for a model that is not this package's
+        RateStateModel — from two `model.evaluate()` calls on the host, the reference's own steps."""
         eng = self._engine()
-        self._init_chains(eng, np.array([[float(self.qstart)]]))
-        eng._chain_owner = self
-        if self._vstart_override is not None:
-            ov = self._vstart_override
-            eng.set_state(V=np.reshape(float(ov(self) if callable(ov) else ov), (1, 1, 1)))
-        _, _, std2, V = eng.get_state()
-        self.std2 = [float(std2[0])]
-        self.Vstart = V.reshape(1, 1).copy()
-        self.model.Dc = self.qstart * (1 + 1e-6)  # the reference leaves the model perturbed (MCMC.py:251)
+        if self._device_model():
+            self._init_chains(eng, np.array([[float(self.qstart)]]))
+            eng._chain_owner = self._chain_key()
+            _, _, std2, V = eng.get_state()
+            self.std2 = [float(std2[0])]
+            self.Vstart = V.reshape(1, 1).copy()
+            self.model.Dc = self.qstart * (1 + 1e-6)  # the reference leaves the model perturbed (MCMC.py:251)
+            return
+        data = np.asarray(self.data, dtype=np.float64).reshape(1, -1)
+        self.model.Dc = self.qstart
+        acc = np.asarray(self.evaluate_model(), dtype=np.float64).reshape(1, -1)           # MCMC.py:245-248
+        self.model.Dc = self.model.Dc * (1 + 1e-6)                                         # :251
+        acc_dq = np.asarray(self.evaluate_model(), dtype=np.float64).reshape(1, -1)        # :254
+        self.std2 = [np.sum((acc - data) ** 2, axis=1).item() / (acc.shape[1] - len(self.qpriors))]   # :261
+        X = ((acc_dq - acc) / (self.model.Dc * 1e-6)).T                                    # :264, perturbed Dc in the denominator
+        self.Vstart = self.std2[-1] * np.linalg.inv(X.T @ X)                               # :265-266
 
     # ---- the hot loop -------------------------------------------------------------------
     def sample(self, MAKE_ANIMATIONS=False):
         """One chain, nsamples proposals → ndarray (1, nsamples + 1 - nburn)  (MCMC.py:391-544)."""
         eng = self._engine()
+        if not self._device_model():
+            return self._sample_host_model(eng, MAKE_ANIMATIONS)
         N = len(self.data)
         burn = self.replay_reference_rng
         self.compute_initial_covariance()
@@ -214,6 +261,47 @@ class MCMC:
             self._animate(qparams)
         return qparams[:, self.nburn:]
 
+    def _sample_host_model(self, eng, MAKE_ANIMATIONS):
+        """sample() for ANY model object with `.Dc` and `.evaluate()` (the reference's contract, MCMC.py:65-66, 127): the
+        host calls the model exactly where the reference does — so whatever the model draws from NumPy's global stream
+        is drawn in the reference's order — and every chain step (proposal, box test, accept test, sigma^2, adaptation)
+        runs on the device on the sum of squares it is handed."""
+        N = len(self.data)
+        self.compute_initial_covariance()                                   # MCMC.py:464
+        ssq0 = float(self.SSqcalc(np.array([[float(self.qstart)]]))[0, 0])  # :468
+        lo, hi = self.qstart_limits[:, 0], self.qstart_limits[:, 1]
+        eng.mcmc_init_state([[float(self.qstart)]], [ssq0], [float(self.std2[-1])], np.reshape(self.Vstart, (1, 1, 1)), lo, hi,
+                            n0=self.n0, prior_len=len(self.qpriors), adapt_mode=self._adapt_mode(), adapt_interval=self.adapt_interval)
+        eng._chain_owner = self._chain_key()
+        aval = 0.5 * (self.n0 + N)
+        qparams = np.empty((1, self.nsamples + 1))
+        qparams[0, 0] = self.qstart
+        std2 = list(self.std2)
+        iaccept = 0
+        for isample in range(self.nsamples):
+            z = np.array([[np.random.standard_normal()]])  # the single normal multivariate_normal consumes (MCMC.py:497)
+            q_new, inb = eng.mcmc_propose(z)
+            u, ssq_new = 1.0, 0.0
+            if inb[0]:  # MCMC.py:322-331: the model is evaluated, then the uniform is drawn
+                ssq_new = float(self.SSqcalc(q_new.reshape(-1, 1))[0, 0])
+                u = np.random.rand()
+            g = np.random.standard_gamma(aval)
+            tq, ts, ta = eng.mcmc_replay_ssq(z.reshape(1, 1, 1), np.array([[u]]), np.array([[g]]), np.array([[ssq_new]]))
+            accept = bool(ta[0, 0])
+            iaccept += accept
+            qparams[0, isample + 1] = float(tq[0, 0, 0])
+            std2.append(float(ts[0, 0]))
+            if self.verbose:
+                print(isample, accept)
+                print("Generated Sample ---- ", q_new.reshape(-1, 1))
+        if self.verbose:
+            print("acceptance ratio:", iaccept / self.nsamples)
+        self.std2 = np.asarray(std2)[self.nburn:]
+        self.acceptance_ratio = iaccept / self.nsamples
+        if MAKE_ANIMATIONS:
+            self._animate(qparams)
+        return qparams[:, self.nburn:]
+
     def sample_batched(self, n_chains, seed=0, q0=None, jitter=None, n_iters=None, iters_per_launch=None,
                        adapt_mode=None, mem="device", device=-1, chain_offset=0, keep="post_burn", thin=1):
         """Throughput path (additive): n_chains independent chains, Philox variates on device.
@@ -233,6 +321,9 @@ class MCMC:
             if jitter is not None:
                 q0[:, 0] = [np.random.default_rng([seed, int(g)]).uniform(*jitter) for g in gids]
         q0 = np.asarray(q0, dtype=np.float64).reshape(n_chains, -1)
+        if not self._device_model():
+            raise TypeError("sample_batched integrates the model on the device: `model` must be this package's RateStateModel "
+                            "(sample() takes any model object with .Dc and .evaluate())")
         eng = Engine(mem=mem, device=device)
         try:
             eng.set_model(self.model, getattr(self.model, "substeps", 1))

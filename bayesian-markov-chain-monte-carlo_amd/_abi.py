@@ -23,6 +23,10 @@ FLAG_DOP853 = 4
 ADAPT_NONE, ADAPT_REFERENCE_DICT, ADAPT_AM = 0, 1, 2
 ADAPT_MODES = {"none": ADAPT_NONE, "reference_dict": ADAPT_REFERENCE_DICT, "am": ADAPT_AM}
 MAX_PARAMS = 3
+ERR_NOT_POSDEF = -6
+# rsf_mcmc_counters: index = RSF_CNT_* of include/rsf_abi.h
+COUNTERS = ("accepted", "evaluated", "nonfinite", "out_of_bounds", "early_rejected", "wave_solves", "wave_skips",
+            "steps_tight", "steps_narrow", "steps_wide", "steps_full", "steps_redone", "lane_steps")
 
 
 class RsfError(RuntimeError):
@@ -98,6 +102,10 @@ PROTOTYPES = {
     "rsf_mcmc_run": (c_int, [c_void_p, c_int64, _P, _P, _P]),
     "rsf_mcmc_replay": (c_int, [c_void_p, c_int64, _P, _P, _P, _P, _P, _P]),
     "rsf_mcmc_stats": (c_int, [c_void_p, POINTER(c_int64), POINTER(c_int64), POINTER(c_int64), POINTER(c_int64)]),
+    "rsf_mcmc_counters": (c_int, [c_void_p, POINTER(c_int64), c_int32]),
+    "rsf_mcmc_init_state": (c_int, [c_void_p, POINTER(McmcConfig), _P, _P, _P, _P]),
+    "rsf_mcmc_propose": (c_int, [c_void_p, _P, _P, _P]),
+    "rsf_mcmc_replay_ssq": (c_int, [c_void_p, c_int64, _P, _P, _P, _P, _P, _P, _P]),
     "rsf_pool_summary": (c_int, [c_void_p, c_int64, _P, c_int64, POINTER(c_double)]),
     "rsf_pool_kde": (c_int, [c_void_p, c_int64, _P, c_int64, c_int32, _P, c_double, _P]),
     "rsf_pool_histogram": (c_int, [c_void_p, c_int64, _P, c_int64, c_int32, c_double, c_double, _P]),

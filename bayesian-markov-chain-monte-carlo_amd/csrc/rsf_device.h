@@ -139,7 +139,7 @@ __device__ __forceinline__ void eval_full(double ms, double x, const Lane &L, co
   rx = fm::rcp(x);
 }
 
-enum Tier : int { TIGHT = 0, NARROW = 1, WIDE = 2 };
+enum Tier : int { TIGHT = 0, NARROW = 1, WIDE = 2, FULL = 3 };  // FULL: a full evaluation at every stage (struct Wave)
 
 // the TIGHT and NARROW tiers' representation of 1/x (struct State)
 template <int T>
@@ -165,11 +165,13 @@ __device__ __forceinline__ void resync_t(State &s, const Lane &L, const Consts &
 // (w', 1/x') at (ms + dms, x1 = x + dx) from (w, rx) at (ms, x).  With rho = dx/x (= dtheta/theta) and
 // dlt = dk - (b/a) log1p(rho), dk = dmu/a = kia*dms:   w' = w exp(dlt),   1/x' = (1/x)/(1 + rho),
 // by short series — the same function of (ms', x') to rounding inside the tier's guard region:
-//   tier     |rho| <   |dlt| <   log1p to     expm1 to       1/x'                              truncation
-//   TIGHT    2^-20     2^-9      rho^2/2      dlt^4/24       1 - rho + rho^2 (no Newton step)  rho^3 < 2^-60; expm1: < 2.4e-16 at the
-//            (its two half-step stages: |dlt| < 2^-10, truncation < 8e-18 relative)              guard's edge (1 ulp), 8e-18 at |dlt| = 1e-3
-//   NARROW   2^-14     2^-7      rho^3/3      dlt^6/720      1 - rho + rho^2 - rho^3 (none)    rho^4 < 2^-56; expm1: < 4.5e-17
-//   WIDE     2^-7      2^-6      rho^7/7      dlt^7/5040     1st-order start + 2 Newton steps  < 1e-19, rho^8 < 2^-56
+//   tier     |rho| <   |dlt| <   log1p to     expm1 to       1/x' = (1/x)(1 + q), q =                 truncation
+//   TIGHT    2^-20     2^-9      rho^2/2      dlt^4/24       -rho + rho^2                             rho^3 < 2^-60; expm1: < 2.4e-16 at the
+//            (its two half-step stages: |dlt| < 2^-10, truncation < 8e-18 relative)                     guard's edge (1 ulp), 8e-18 at |dlt| = 1e-3
+//   NARROW   2^-14     2^-7      rho^3/3      dlt^6/720      -rho + rho^2 - rho^3                     rho^4 < 2^-56; expm1: < 4.5e-17
+//   WIDE     2^-11     2^-5      rho^4/4      dlt^8/40320    -rho + rho^2 - rho^3 + rho^4             rho^5 < 2^-55; expm1: < 2.4e-18
+// (guard_ok holds exactly these bounds; no tier takes a Newton step.)  Beyond WIDE: the FULL tier, log / exp / reciprocal at
+// every stage (struct Wave).
 // Guard tracks the largest |rho| / |dlt| seen since it was last reset — through the HIGH WORD of each double read as
 // a float: for |x| < 2^1017 that reading is finite and monotone in |x|, the thresholds are powers of two (exact in the
 // high word), and two values fold into one v_max3_f32 with |.| as source modifiers (4 instructions per step instead
@@ -362,11 +364,8 @@ __device__ __forceinline__ void stage_chunk(double *lds, const Consts &K, int k0
   __syncthreads();
 }
 
-// RK4 steps go in PAIRS through straight-line code, so loop control, the resync test, the increment guard and the
-// LDS address are paid once per two steps and no register copies are needed to rotate the state.  A failed guard
-// redoes the pair from `save` with full evaluations and, for the TIGHT and NARROW tiers, hands the rest of the
-// chunk to the next wider tier (wave-uniform decision).  S1: one step per output sample (the BASELINE configs),
-// both steps of a pair emit a sample; otherwise a sample is emitted every K.S steps (wave-uniform phase counter).
+// Output bookkeeping of a chunk.  S1: one step per output sample (the BASELINE configs), every step of a trip emits a
+// sample; otherwise a sample is emitted every K.S steps (wave-uniform phase counter).
 struct Emit {            // output bookkeeping of a chunk
   int ko;                // next output sample of the chunk (0 .. kn-1)
   int phase;             // RK4 steps since the last emitted sample (S > 1 only)
@@ -377,9 +376,9 @@ struct Emit {            // output bookkeeping of a chunk
 // `obs` is the observation at that sample (read from LDS by the caller, early, so its latency is hidden)
 template <bool WANT_SSQ, bool WANT_ACC>
 __device__ __forceinline__ void emit_at(double vnow, double vprev, int ko, double obs, const Consts &K, int k0,
-                                        double &ssq, double *acc_out, int64_t stride) {
+                                        double &ssq, bool active, double *acc_out, int64_t stride) {
   const double ak = (vnow - vprev) * K.inv_dt;
-  if (WANT_ACC) acc_out[(int64_t)(k0 + ko) * stride] = ak;
+  if (WANT_ACC && active) acc_out[(int64_t)(k0 + ko) * stride] = ak;
   if (WANT_SSQ) {
     const double r = ak - obs;
     ssq = __builtin_fma(r, r, ssq);
@@ -389,8 +388,8 @@ __device__ __forceinline__ void emit_at(double vnow, double vprev, int ko, doubl
 // the same sample straight from the step's derivative sum (one step per output sample): ak = cacc vk * dvs
 template <bool WANT_SSQ, bool WANT_ACC>
 __device__ __forceinline__ void emit_incr(double dvs, int ko, double obs, const Lane &L, int k0, double &ssq,
-                                          double *acc_out, int64_t stride) {
-  if (WANT_ACC) acc_out[(int64_t)(k0 + ko) * stride] = dvs * L.cv;
+                                          bool active, double *acc_out, int64_t stride) {
+  if (WANT_ACC && active) acc_out[(int64_t)(k0 + ko) * stride] = dvs * L.cv;
   if (WANT_SSQ) {
     const double r = __builtin_fma(dvs, L.cv, -obs);  // one rounding; identical with and without WANT_ACC
     ssq = __builtin_fma(r, r, ssq);
@@ -399,8 +398,8 @@ __device__ __forceinline__ void emit_incr(double dvs, int ko, double obs, const 
 
 template <bool WANT_SSQ, bool WANT_ACC>
 __device__ __forceinline__ void emit_sample(double vnow, Emit &em, double obs, const Consts &K, int k0, double &ssq,
-                                            double *acc_out, int64_t stride) {
-  emit_at<WANT_SSQ, WANT_ACC>(vnow, em.vprev, em.ko, obs, K, k0, ssq, acc_out, stride);
+                                            bool active, double *acc_out, int64_t stride) {
+  emit_at<WANT_SSQ, WANT_ACC>(vnow, em.vprev, em.ko, obs, K, k0, ssq, active, acc_out, stride);
   em.vprev = vnow;
   ++em.ko;
 }
@@ -430,172 +429,219 @@ __device__ __forceinline__ void trip_cold(const double *v, const Lane &L, const 
   eval_full_t<T>(s, L, K);
 }
 
-// integrates RK4 steps [r, nsteps) of the chunk two at a time; returns the first step not yet integrated
-template <bool DAMP, bool WANT_SSQ, bool WANT_ACC, int T, bool S1>
-__device__ __forceinline__ int integrate_pairs(const double *lds, const double *ld, const Consts &K, Lane L, int k0, int r,
-                                               int nsteps, State &s, Emit &em, double &ssq, double *acc_out, int64_t stride) {
-  set_tier<T>(L);
-  for (; r + 2 <= nsteps; r += 2) {
-    const double *v = lds + 2 * r;
-    // observations this pair can complete, read before the arithmetic (S > 1: at most one sample per pair)
-    const double obs0 = WANT_SSQ ? ld[S1 ? r : em.ko] : 0.0, obs1 = (WANT_SSQ && S1) ? ld[r + 1] : 0.0;
-    if (r != 0 && (r & (kResync - 1)) == 0) resync_t<T>(s, L, K);
-    const State save = s;
-    double dv[2];
-    const bool bad = trip_fast<DAMP, T, 2>(v, L, K, s, dv);
-    const unsigned long long badmask = __builtin_amdgcn_ballot_w64(bad);  // wave-uniform, straight from the compares
-    if (__builtin_expect(badmask != 0, 0)) {  // scalar branch: the hot path carries no exec-mask bookkeeping
-      if (bad) {
-        s = save;
-        trip_cold<DAMP, T, 2>(v, L, K, s, dv);
-      }
-    }
-    if (S1) {  // sample index == step index: no bookkeeping, and V is not carried at all
-      emit_incr<WANT_SSQ, WANT_ACC>(dv[0], r, obs0, L, k0, ssq, acc_out, stride);
-      emit_incr<WANT_SSQ, WANT_ACC>(dv[1], r + 1, obs1, L, k0, ssq, acc_out, stride);
-    } else {
-      const double vmid = __builtin_fma(L.h6v, dv[0], save.V);
-      s.V = __builtin_fma(L.h6v, dv[1], vmid);
-      if (++em.phase == K.S) { em.phase = 0; emit_sample<WANT_SSQ, WANT_ACC>(vmid, em, obs0, K, k0, ssq, acc_out, stride); }
-      if (++em.phase == K.S) { em.phase = 0; emit_sample<WANT_SSQ, WANT_ACC>(s.V, em, obs0, K, k0, ssq, acc_out, stride); }
-    }
-    if (T != WIDE && badmask != 0) return r + 2;
-  }
-  return r;
+// ---------------------------------------------------------------------------------------------
+// Wave-level control of one forward solve.  Every member is wave-uniform (ballots, step counts), i.e. lives in SGPRs.
+//
+// alive    lanes whose result can still matter: in bounds (the caller's activity mask) and not yet CERTAINLY REJECTED.
+//          The sum of squares is a sum of non-negative terms, so its partial sums only grow, and the accept test
+//          (MCMC.py:327-331) is monotone in SSq: once a lane's running sum exceeds `thr` — the caller's conservative bound
+//          on the largest SSq that could still be accepted with this iteration's uniform — the proposal is rejected
+//          whatever the rest of the series adds.  Such a lane stops counting: its guard trips are ignored, it no longer
+//          holds its wave in a wider tier, and a wave with no lane left ends the solve.  Nothing observable changes: a
+//          rejected proposal leaves the chain where it was, and its SSq is never stored.
+// need[]   need[T-1] = lanes that cannot run a tier tighter than T (T = NARROW, WIDE, FULL): the a-priori bound of the lane's
+//          mu increment (|V_l - v| <~ 1.2 V_ref against the tiers' |dlt| guards), escalated when the lane's guard trips.
+//          The wave's tier is the widest one an ALIVE lane needs, re-decided whenever that set changes — so a stiff
+//          small-Dc proposal costs its wave the wider tier only until its sum of squares has disqualified it.
+// FULL     the full-evaluation tier (log / exp / reciprocal at every stage, exact whatever the increments): entered by a lane
+//          whose WIDE guard trips, left again after kFullRetry steps to try WIDE once more (`stiff` lanes, whose a-priori
+//          bound is beyond 2^-3, stay).  Until round 4 a tripped WIDE trip was redone cold and the next trip tried the
+//          fast step again: a wave with one stiff lane paid fast + cold on every trip.
+// ---------------------------------------------------------------------------------------------
+constexpr int kFullRetry = 32;
+struct Wave {
+  unsigned long long alive;
+  unsigned long long need[3];
+  unsigned long long stiff;
+  int next_resync;   // chunk-local step at which (w, Rh) are next re-evaluated in full (kResync)
+  int full_run;      // steps since the FULL tier was (re-)entered
+  // statistics of this solve (rsf_mcmc_counters): wave-steps per tier, wave-steps of fast trips thrown away by a tripped
+  // guard, and the sum over steps of the number of alive lanes (lane utilisation = lane_steps / (64 * all steps))
+  uint32_t steps[4], redone, lane_steps;
+};
+
+__device__ __forceinline__ unsigned long long ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+__device__ __forceinline__ bool lane_in(unsigned long long mask) { return (mask >> (threadIdx.x & 63)) & 1; }
+
+// (the statistics members are the caller's to zero: they accumulate over the solves of a launch)
+__device__ __forceinline__ void wave_begin(Wave &W, bool active, const Lane &L, const Consts &K) {
+  const double dk = 1.2 * K.V_ref * K.h * L.kia;
+  W.alive = ballot(active);
+  W.need[0] = ballot(active && !(dk < 0x1.0p-9));
+  W.need[1] = ballot(active && !(dk < 0x1.0p-7));
+  W.need[2] = W.stiff = ballot(active && !(dk < 0x1.0p-3));
+  W.next_resync = kResync;
+  W.full_run = 0;
 }
 
-// NU steps per trip through the loop (straight-line code): the resync test, the guard compare and
-// the branch that waits for it, and the LDS addressing are paid per TRIP — and a lone wave sits out the whole latency
-// of that compare-and-branch, ~150 cycles, whatever the trip holds (2 -> 4 -> 8 steps per trip: +12 %, +14 % at cfg1).
-// A tripped guard redoes the trip with full evaluations; TIGHT and NARROW then hand the rest of the chunk to the next
-// wider tier (`tripped`), like integrate_pairs, which takes whatever remainder (< NU steps) is left.
+__device__ __forceinline__ int wave_tier(const Wave &W) {
+  return (W.need[2] & W.alive) ? FULL : ((W.need[1] & W.alive) ? WIDE : ((W.need[0] & W.alive) ? NARROW : TIGHT));
+}
+
+// samples completed by a trip of NU steps starting at chunk step r (dv[j]: the steps' V-derivative sums).  S1: every step
+// is a sample, its observation obs[j] read ahead by the caller; else one every K.S steps (wave-uniform phase counter), V
+// carried, the observation read from LDS where the sample completes (at most one per K.S >= 2 steps: selecting among
+// observations read ahead by a run-time count costs a scratch array once that count is known to be scalar).
+template <bool WANT_SSQ, bool WANT_ACC, bool S1, int NU>
+__device__ __forceinline__ void emit_trip(const double (&dv)[NU], const double (&obs)[NU], const double *ld, int r, State &s, Emit &em,
+                                          const Lane &L, const Consts &K, int k0, double &ssq, bool active, double *acc_out, int64_t stride) {
+  if (S1) {
+#pragma unroll
+    for (int j = 0; j < NU; ++j) emit_incr<WANT_SSQ, WANT_ACC>(dv[j], r + j, obs[j], L, k0, ssq, active, acc_out, stride);
+  } else {
+#pragma unroll
+    for (int j = 0; j < NU; ++j) {
+      s.V = __builtin_fma(L.h6v, dv[j], s.V);
+      if (++em.phase == K.S) {
+        em.phase = 0;
+        const double o = WANT_SSQ ? ld[em.ko] : 0.0;
+        emit_sample<WANT_SSQ, WANT_ACC>(s.V, em, o, K, k0, ssq, active, acc_out, stride);
+      }
+    }
+  }
+}
+
+// NU steps per trip through the loop (straight-line code): the resync test, the guard compare and the branch that waits
+// for it, and the LDS addressing are paid per TRIP — and a lone wave sits out the whole latency of that
+// compare-and-branch, ~150 cycles, whatever the trip holds (2 -> 4 -> 8 steps per trip: +12 %, +14 % at cfg1).
+// Integrates trips of tier T from chunk step r while the wave's tier stays T; returns the first step not integrated.
+// It comes back early — for integrate_tiers to re-decide the tier — when an alive lane's guard tripped (that trip is redone
+// with full evaluations for the lane, which from then on needs the next wider tier), when no alive lane needs a tier this
+// wide any more, or when no lane is alive.  All of that is ONE scalar branch at the end of the trip; the early-rejection
+// compare uses the sum of squares as the PREVIOUS trip left it, so the branch never waits for the trip's last result.
 constexpr int kTightUnroll = 8;  // steps per trip of the TIGHT loop (the one-parameter sampler runs 2 * kTightUnroll, rsf_kernels.h)
 constexpr int kNarrowUnroll = 8, kWiderUnroll = 4;  // NARROW; WIDE
 template <bool DAMP, bool WANT_SSQ, bool WANT_ACC, int T, bool S1, int NU>
 __device__ __forceinline__ int integrate_multi(const double *lds, const double *ld, const Consts &K, Lane L, int k0, int kn, int r,
-                                               int nsteps, State &s, Emit &em, double &ssq, double *acc_out, int64_t stride,
-                                               bool &tripped) {
-  static_assert(NU >= 2 && (kResync % NU) == 0, "the resync test looks at the first step of a trip");
+                                               int nsteps, State &s, Emit &em, double &ssq, double thr, bool active, double *acc_out,
+                                               int64_t stride, Wave &W) {
+  static_assert(NU >= 1 && (kResync % NU) == 0, "trip lengths divide the resync interval");
   set_tier<T>(L);
   for (; r + NU <= nsteps; r += NU) {
+    const unsigned long long deadmask = WANT_SSQ ? ballot(ssq > thr) : 0ull;  // NaN compares false: such a lane runs on
     const double *v = lds + 2 * r;
-    // observations this trip can complete, read before the arithmetic (substeps > 1: at most NU/2 samples per trip,
-    // the next ones in line — clamped reads, unused ones cost an LDS read each)
-    constexpr int NO = S1 ? NU : NU / 2;
-    double obs[NO], dv[NU];
+    // one step per sample: the observations this trip completes, read before the arithmetic (a lone wave has nothing
+    // else to hide the LDS latency behind)
+    double obs[NU], dv[NU];
 #pragma unroll
-    for (int j = 0; j < NO; ++j) obs[j] = WANT_SSQ ? ld[S1 ? r + j : min(em.ko + j, kn - 1)] : 0.0;
-    if (r != 0 && (r & (kResync - 1)) == 0) resync_t<T>(s, L, K);
+    for (int j = 0; j < NU; ++j) obs[j] = (WANT_SSQ && S1) ? ld[r + j] : 0.0;
+    if (r >= W.next_resync) {
+      resync_t<T>(s, L, K);
+      W.next_resync = (r & ~(kResync - 1)) + kResync;
+    }
     const State save = s;
     const bool bad = trip_fast<DAMP, T, NU>(v, L, K, s, dv);
-    const unsigned long long badmask = __builtin_amdgcn_ballot_w64(bad);  // wave-uniform, straight from the compares
+    const unsigned long long badmask = ballot(bad) & W.alive;  // wave-uniform, straight from the compares
+    W.steps[T] += NU;
+    W.lane_steps += NU * (uint32_t)__builtin_popcountll(W.alive);
     if (__builtin_expect(badmask != 0, 0)) {  // scalar branch: the hot path carries no exec-mask bookkeeping
-      if (bad) {
+      if (lane_in(badmask)) {
         s = save;
         trip_cold<DAMP, T, NU>(v, L, K, s, dv);
       }
+      W.need[T] |= badmask;
+      W.redone += NU;
+      W.full_run = 0;
     }
-    if (S1) {
-#pragma unroll
-      for (int j = 0; j < NU; ++j) emit_incr<WANT_SSQ, WANT_ACC>(dv[j], r + j, obs[j], L, k0, ssq, acc_out, stride);
-    } else {
-      int used = 0;  // wave-uniform: every lane emits the same samples
-      s.V = save.V;
-#pragma unroll
-      for (int j = 0; j < NU; ++j) {
-        s.V = __builtin_fma(L.h6v, dv[j], s.V);
-        if (++em.phase == K.S) {
-          em.phase = 0;
-          double o = obs[0];
-#pragma unroll
-          for (int i = 1; i < NO; ++i) o = used == i ? obs[i] : o;
-          emit_sample<WANT_SSQ, WANT_ACC>(s.V, em, o, K, k0, ssq, acc_out, stride);
-          ++used;
-        }
-      }
-    }
-    if (T != WIDE && badmask != 0) { tripped = true; return r + NU; }
+    emit_trip<WANT_SSQ, WANT_ACC, S1, NU>(dv, obs, ld, r, s, em, L, K, k0, ssq, active, acc_out, stride);
+    W.alive &= ~deadmask;
+    if (badmask != 0 || W.alive == 0 || (T != TIGHT && (W.need[T - 1] & W.alive) == 0)) return r + NU;
   }
   return r;
 }
 
-// Wave-uniform choice of the starting tier — a speed decision only: every tier is exact to rounding inside its guard, and
-// a tier whose guard trips redoes that trip in full and hands over to the next wider one.  TIGHT and NARROW are tried whenever
-// the mu increment allows it (|V_l - v| <~ 1.2 V_ref against their |dlt| guards 2^-9 / 2^-7): theta tracks its steady state
-// closely (|dtheta/theta| ~ 1e-7 per stage at Dc ~ 1000, h = 0.1), which no a-priori bound captures.
+// The FULL tier: one step per trip with a full evaluation at every stage (rk4_cold), on the plain state (ms, x) — w and
+// 1/x are not carried.  Runs while an alive lane needs it; every kFullRetry steps the lanes that came here from a tripped
+// WIDE guard are sent back to try WIDE again.
+template <bool DAMP, bool WANT_SSQ, bool WANT_ACC, bool S1>
+__device__ __forceinline__ int integrate_full(const double *lds, const double *ld, const Consts &K, const Lane &L, int k0, int kn, int r,
+                                              int nsteps, State &s, Emit &em, double &ssq, double thr, bool active, double *acc_out,
+                                              int64_t stride, Wave &W) {
+#pragma unroll 1
+  for (; r < nsteps; ++r) {
+    const unsigned long long deadmask = WANT_SSQ ? ballot(ssq > thr) : 0ull;
+    const double *v = lds + 2 * r;
+    const double obs[1] = {(WANT_SSQ && S1) ? ld[r] : 0.0};
+    const double dv[1] = {rk4_cold<DAMP>(s, v[0], v[1], v[2], L, K)};
+    W.steps[FULL] += 1;
+    W.lane_steps += (uint32_t)__builtin_popcountll(W.alive);
+    emit_trip<WANT_SSQ, WANT_ACC, S1, 1>(dv, obs, ld, r, s, em, L, K, k0, ssq, active, acc_out, stride);
+    W.alive &= ~deadmask;
+    if (++W.full_run >= kFullRetry) {
+      W.need[2] &= W.stiff;
+      W.full_run = 0;
+    }
+    if (W.alive == 0 || (W.need[2] & W.alive) == 0) return r + 1;
+  }
+  return r;
+}
+
+// Wave-uniform choice of the starting tier of the init kernel's lockstep trajectories (rsf_kernels.h) — a speed decision
+// only: every tier is exact to rounding inside its guard.  TIGHT and NARROW are tried whenever the mu increment allows it
+// (|V_l - v| <~ 1.2 V_ref against their |dlt| guards 2^-9 / 2^-7): theta tracks its steady state closely (|dtheta/theta| ~ 1e-7
+// per stage at Dc ~ 1000, h = 0.1), which no a-priori bound captures.  (The solve below decides the same per lane: wave_begin.)
 __device__ __forceinline__ int start_tier(const Lane &L, const Consts &K) {
   const double dk = 1.2 * K.V_ref * K.h * L.kia;
   return !__any(!(dk < 0x1.0p-9)) ? TIGHT : (!__any(!(dk < 0x1.0p-7)) ? NARROW : WIDE);
 }
 
+// trips of tier T from chunk step r (at least two steps are left): long trips while they fit, then pairs
+template <bool DAMP, bool WANT_SSQ, bool WANT_ACC, int T, bool S1, int NU>
+__device__ __forceinline__ int integrate_tier(const double *lds, const double *ld, const Consts &K, const Lane &L, int k0, int kn, int r,
+                                              int nsteps, State &s, Emit &em, double &ssq, double thr, bool active, double *acc_out,
+                                              int64_t stride, Wave &W) {
+  if (r + NU <= nsteps) return integrate_multi<DAMP, WANT_SSQ, WANT_ACC, T, S1, NU>(lds, ld, K, L, k0, kn, r, nsteps, s, em, ssq, thr, active, acc_out, stride, W);
+  return integrate_multi<DAMP, WANT_SSQ, WANT_ACC, T, S1, 2>(lds, ld, K, L, k0, kn, r, nsteps, s, em, ssq, thr, active, acc_out, stride, W);
+}
+
 template <bool DAMP, bool WANT_SSQ, bool WANT_ACC, bool S1, int NUT>
 __device__ __forceinline__ void integrate_tiers(const double *lds, const double *ld, const Consts &K, const Lane &L, int k0,
-                                                int kn, State &s, double &ssq, double *acc_out, int64_t stride) {
-  const int tier = start_tier(L, K);
+                                                int kn, State &s, double &ssq, double thr, bool active, double *acc_out, int64_t stride, Wave &W) {
   const int nsteps = S1 ? kn : K.S * kn;
   Emit em = {0, 0, s.V};
   int r = 0;
-  // tiers in order; within a tier the long-trip loop first, then pairs for the remainder;
-  // `t_trip` / `n_trip`: that tier's guard tripped in the long-trip loop, the rest goes to the next wider tier
-  bool t_trip = false, n_trip = false, unused = false;
-  if (tier == TIGHT) {
-    tier_enter<TIGHT>(s, L);
-    r = integrate_multi<DAMP, WANT_SSQ, WANT_ACC, TIGHT, S1, NUT>(lds, ld, K, L, k0, kn, r, nsteps, s, em, ssq, acc_out, stride, t_trip);
-    if (!t_trip) r = integrate_pairs<DAMP, WANT_SSQ, WANT_ACC, TIGHT, S1>(lds, ld, K, L, k0, r, nsteps, s, em, ssq, acc_out, stride);
-    tier_leave<TIGHT>(s, L);
-  }
-  if (tier <= NARROW && r < nsteps) {
-    tier_enter<NARROW>(s, L);
-    r = integrate_multi<DAMP, WANT_SSQ, WANT_ACC, NARROW, S1, kNarrowUnroll>(lds, ld, K, L, k0, kn, r, nsteps, s, em, ssq, acc_out, stride, n_trip);
-    if (!n_trip) r = integrate_pairs<DAMP, WANT_SSQ, WANT_ACC, NARROW, S1>(lds, ld, K, L, k0, r, nsteps, s, em, ssq, acc_out, stride);
-    tier_leave<NARROW>(s, L);
-  }
-  if (r >= nsteps) return;
-  tier_enter<WIDE>(s, L);
-  r = integrate_multi<DAMP, WANT_SSQ, WANT_ACC, WIDE, S1, kWiderUnroll>(lds, ld, K, L, k0, kn, r, nsteps, s, em, ssq, acc_out, stride, unused);
-  r = integrate_pairs<DAMP, WANT_SSQ, WANT_ACC, WIDE, S1>(lds, ld, K, L, k0, r, nsteps, s, em, ssq, acc_out, stride);
-  if (r < nsteps) {  // odd last step of the chunk (it always completes a sample): one WIDE step, cold if its guard trips
-    const double *v = lds + 2 * r;
-    const double obs = WANT_SSQ ? ld[kn - 1] : 0.0;
-    Lane Lw = L;
-    set_tier<WIDE>(Lw);
-    const State save = s;
-    double dv[1];
-    if (__builtin_expect(trip_fast<DAMP, WIDE, 1>(v, Lw, K, s, dv), 0)) {
-      s = save;
-      trip_cold<DAMP, WIDE, 1>(v, L, K, s, dv);
+  W.next_resync = kResync;  // chunk-local; not at a chunk's first step (see kResync)
+  bool scaled = false;      // s.rx holds Rh = hhd / x (the incremental tiers' state) rather than 1 / x
+  while (r < nsteps && W.alive != 0) {
+    const int tier = wave_tier(W);
+    if (tier == FULL) {
+      if (scaled) { tier_leave<WIDE>(s, L); scaled = false; }
+      r = integrate_full<DAMP, WANT_SSQ, WANT_ACC, S1>(lds, ld, K, L, k0, kn, r, nsteps, s, em, ssq, thr, active, acc_out, stride, W);
+      eval_full(s.ms, s.x, L, K, s.w, s.rx);  // (w, 1/x) at the point the incremental tiers — or the next chunk — continue from
+      continue;
     }
-    tier_leave<WIDE>(s, L);
-    if (S1) {
-      emit_incr<WANT_SSQ, WANT_ACC>(dv[0], kn - 1, obs, L, k0, ssq, acc_out, stride);
-    } else {
-      s.V = __builtin_fma(L.h6v, dv[0], s.V);
-      emit_at<WANT_SSQ, WANT_ACC>(s.V, em.vprev, kn - 1, obs, K, k0, ssq, acc_out, stride);
-    }
-  } else {
-    tier_leave<WIDE>(s, L);
+    if (!scaled) { tier_enter<TIGHT>(s, L); scaled = true; }
+    // the chunk's odd last step (it always completes a sample): with the WIDE series whatever the tier — one instance
+    if (nsteps - r == 1) r = integrate_multi<DAMP, WANT_SSQ, WANT_ACC, WIDE, S1, 1>(lds, ld, K, L, k0, kn, r, nsteps, s, em, ssq, thr, active, acc_out, stride, W);
+    else if (tier == TIGHT) r = integrate_tier<DAMP, WANT_SSQ, WANT_ACC, TIGHT, S1, NUT>(lds, ld, K, L, k0, kn, r, nsteps, s, em, ssq, thr, active, acc_out, stride, W);
+    else if (tier == NARROW) r = integrate_tier<DAMP, WANT_SSQ, WANT_ACC, NARROW, S1, kNarrowUnroll>(lds, ld, K, L, k0, kn, r, nsteps, s, em, ssq, thr, active, acc_out, stride, W);
+    else r = integrate_tier<DAMP, WANT_SSQ, WANT_ACC, WIDE, S1, kWiderUnroll>(lds, ld, K, L, k0, kn, r, nsteps, s, em, ssq, thr, active, acc_out, stride, W);
   }
+  if (scaled) tier_leave<WIDE>(s, L);
 }
 
 // Integrate kn output intervals from the staged chunk.  Accumulates the sum of squares
-// (MCMC.py:387) and optionally stores acc time-major.  Called under the lane's activity mask.
+// (MCMC.py:387) and optionally stores acc time-major (`active` lanes only).  Called by whole waves.
 template <bool DAMP, bool WANT_SSQ, bool WANT_ACC, int NUT>
-__device__ __forceinline__ void integrate_chunk(const double *lds, const Consts &K, const Lane &L, int k0,
-                                                int kn, State &s, double &ssq, double *acc_out, int64_t stride) {
+__device__ __forceinline__ void integrate_chunk(const double *lds, const Consts &K, const Lane &L, int k0, int kn, State &s,
+                                                double &ssq, double thr, bool active, double *acc_out, int64_t stride, Wave &W) {
   const double *ld = lds + lds_data_offset(K);
-  if (K.S == 1) integrate_tiers<DAMP, WANT_SSQ, WANT_ACC, true, NUT>(lds, ld, K, L, k0, kn, s, ssq, acc_out, stride);
-  else integrate_tiers<DAMP, WANT_SSQ, WANT_ACC, false, NUT>(lds, ld, K, L, k0, kn, s, ssq, acc_out, stride);
+  if (K.S == 1) integrate_tiers<DAMP, WANT_SSQ, WANT_ACC, true, NUT>(lds, ld, K, L, k0, kn, s, ssq, thr, active, acc_out, stride, W);
+  else integrate_tiers<DAMP, WANT_SSQ, WANT_ACC, false, NUT>(lds, ld, K, L, k0, kn, s, ssq, thr, active, acc_out, stride, W);
 }
 
 // Full forward solve for one lane.  Every thread of the workgroup must call it (chunk staging has barriers);
 // `resident` (workgroup-uniform): the single chunk is already staged, nothing is re-staged.
 // NUT: RK4 steps per trip of the TIGHT loop (integrate_multi); 16 where the kernel's registers allow it (one-parameter
-// sampler), 8 otherwise
+// sampler), 8 otherwise.  thr: a sum of squares above it cannot be accepted (struct Wave; +inf where every lane's result is
+// wanted) — the value returned for a lane that stopped counting is the partial sum that disqualified it.  W: the solve's
+// wave-level control and statistics, for the caller's counters.
 template <bool DAMP, bool WANT_SSQ, bool WANT_ACC, int NUT = kTightUnroll>
 __device__ __forceinline__ double solve(double *lds, const Consts &K, bool resident, bool active, double dc, double a,
-                                        double b, double *acc_out, int64_t stride) {
+                                        double b, double thr, double *acc_out, int64_t stride, Wave &W) {
   const Lane L = make_lane(dc, a, b, K);
   State s = initial_state(dc, L, K);
+  wave_begin(W, active, L, K);
   double ssq = 0.0;
   if (WANT_SSQ && active) {
     const double d0 = K.data[0];  // sample 0 belongs to no chunk: acc[0] = 0, RateStateModel.py:371
@@ -605,7 +651,10 @@ __device__ __forceinline__ double solve(double *lds, const Consts &K, bool resid
   for (int k0 = 1; k0 < K.nout; k0 += K.kc) {
     const int kn = min(K.kc, K.nout - k0);
     if (!resident) stage_chunk(lds, K, k0, kn);
-    if (active) integrate_chunk<DAMP, WANT_SSQ, WANT_ACC, NUT>(lds, K, L, k0, kn, s, ssq, acc_out, stride);
+    // a wave-uniform branch: every lane of a wave with work goes in — the lanes that are not `active` (out of bounds, past
+    // the end of the batch) ride along masked out of W.alive and of the trajectory stores.  (Under `if (active)`, a divergent
+    // branch, everything the solve leaves in W would count as divergent after it and move from scalar to vector registers.)
+    if (W.alive != 0) integrate_chunk<DAMP, WANT_SSQ, WANT_ACC, NUT>(lds, K, L, k0, kn, s, ssq, thr, active, acc_out, stride, W);
   }
   return ssq;
 }
@@ -723,6 +772,39 @@ __device__ __forceinline__ bool window_covariance(const double *ws, const double
 #pragma unroll
     for (int r = 0; r < D; ++r) Vn[p * D + r] = scale * ((wq[p * D + r] - ws[p] * ws[r] / nn) / (nn - 1.0));
   return chol_lower<D>(Vn, Ln);
+}
+
+// np.cov of ONE variable's window as NumPy forms it (numpy/lib/_function_base_impl.py::cov): the mean from np.add.reduce's
+// pairwise summation — fewer than 8 elements one by one from 0; up to 128 (RSF_DICT_MAX_INTERVAL) through eight interleaved
+// accumulators combined pairwise, the remainder one by one (numpy/_core/src/umath/loops_utils.h.src) — then the
+// deviations' dot product times 1 / (n - 1).  The ORDER of that sum is what `reference_dict` adaptation needs: whether the
+// mean of a window of identical samples is that sample (covariance exactly 0: np.linalg.cholesky raises and the reference
+// keeps its proposal, MCMC.py:524-527) or one ulp off (covariance ~1e-31: the Cholesky "succeeds" and the reference's
+// proposal collapses to ~1e-8) depends on the sample's low bits through exactly these additions.  a(k): sample k.
+template <typename F>
+__device__ __forceinline__ double np_cov_1d(F a, int n) {
+  double sum;
+  if (n < 8) {
+    sum = 0.0;
+    for (int i = 0; i < n; ++i) sum += a(i);
+  } else {
+    double r[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = a(j);
+    int i = 8;
+    for (; i < n - (n % 8); i += 8)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) r[j] += a(i + j);
+    sum = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    for (; i < n; ++i) sum += a(i);
+  }
+  const double avg = sum / (double)n;
+  double c = 0.0;
+  for (int k = 0; k < n; ++k) {
+    const double dlt = a(k) - avg;
+    c = __builtin_fma(dlt, dlt, c);
+  }
+  return c * (1.0 / (double)(n - 1));
 }
 
 // wave64 sum via DPP-free shuffles; result valid in lane 0

@@ -75,8 +75,9 @@ struct rsf_ctx {
   DevBuf vl;
   // chains
   bool have_chains = false;
+  bool external_chains = false;  // made by rsf_mcmc_init_state: no observation, advanced by rsf_mcmc_replay_ssq only
   rsf_mcmc_config mc{};
-  DevBuf data, q, ssq, std2, V, wref, wsum, wsq, wn, stats;
+  DevBuf data, q, ssq, std2, V, wref, wsum, wsq, wn, wbuf, stats;
   int64_t group_chains = 0;  // chains per observation group (0: one series)
   int64_t iters_done = 0;
   // staging for RSF_MEM_HOST callers
@@ -191,10 +192,12 @@ size_t mcmc_table_bytes(const rsf_ctx *c) {
 }
 
 size_t mcmc_lds_bytes(const rsf_ctx *c) {
-  if (c->mc.n_params != 3) return mcmc_table_bytes(c);
-  // per lane: the six doubles of a chain's Cholesky factor (two chains in the float32 sampler); the float64 RK4 sampler
-  // also parks the chain's point, sigma^2 and SSq there across the forward solve (five more)
-  const size_t slots = mode_of(c) == RK4_F32 ? 12 : (mode_of(c) == RK4_F64 ? 11 : 6);
+  // per lane behind the table chunk: the float64 RK4 sampler parks the chain's point, sigma^2, SSq and log u there across
+  // the forward solve (kParkSlots: 4 doubles for one parameter; 12 for three, whose first six hold the chain's Cholesky
+  // factor); the other samplers keep only the factor of a three-parameter chain (two chains per lane in float32)
+  const int d = c->mc.n_params;
+  size_t slots = d == 3 ? (mode_of(c) == RK4_F32 ? 12 : 6) : 0;
+  if (mode_of(c) == RK4_F64) slots = d == 3 ? kParkSlots<3> : kParkSlots<1>;
   return mcmc_table_bytes(c) + slots * sizeof(double) * (size_t)c->block;
 }
 
@@ -384,10 +387,21 @@ int run_replay_graph(rsf_ctx *c, const Consts &K, McmcArgs A, const double *z, c
   return RSF_OK;
 }
 
-int run_mcmc(rsf_ctx *c, int64_t n_iters, const double *z, const double *u, const double *g, double *tq,
+// the chain logic alone on caller-supplied sums of squares (rsf_mcmc_replay_ssq): no tables, no solve, one chain per lane
+template <int D>
+int launch_mcmc_inject(rsf_ctx *c, const Consts &K, McmcArgs A) {
+  A.lc_off = 0;  // nothing is staged: the per-lane slots of a three-parameter chain start at the base of LDS
+  const size_t lds = kParkSlots<D> * sizeof(double) * (size_t)c->block;
+  hipLaunchKernelGGL((mcmc_kernel<D, false, true, RK4_F64, true>), dim3(grid_for(c, A.C)), dim3(c->block), lds, c->stream, K, A);
+  return RSF_OK;
+}
+
+int run_mcmc(rsf_ctx *c, int64_t n_iters, const double *z, const double *u, const double *g, const double *ssq_new, double *tq,
              double *ts, uint8_t *ta, bool replay) {
   if (!c || n_iters < 0) return fail(RSF_ERR_INVALID, "rsf_mcmc_run: bad argument");
   if (!c->have_chains) return fail(RSF_ERR_STATE, "rsf_mcmc_run: call rsf_mcmc_init first");
+  if (c->external_chains && !ssq_new)
+    return fail(RSF_ERR_STATE, "chains made by rsf_mcmc_init_state have no observation: advance them with rsf_mcmc_replay_ssq");
   if (n_iters == 0) return RSF_OK;
   DeviceGuard guard(c->device);
   if (!guard.ok) return fail(RSF_ERR_DEVICE, "rsf_mcmc_run: cannot select device %d", c->device);
@@ -404,9 +418,10 @@ int run_mcmc(rsf_ctx *c, int64_t n_iters, const double *z, const double *u, cons
   A.lc_off = (int32_t)(mcmc_table_bytes(c) / sizeof(double));
   A.q = (double *)c->q.p; A.ssq = (double *)c->ssq.p; A.std2 = (double *)c->std2.p; A.V = (double *)c->V.p;
   A.wref = (double *)c->wref.p; A.wsum = (double *)c->wsum.p; A.wsq = (double *)c->wsq.p; A.wn = (int32_t *)c->wn.p;
+  A.wbuf = (double *)c->wbuf.p;
   A.stats = (unsigned long long *)c->stats.p;
   int rc;
-  if (replay && host_mem(c) && n_iters == 1 && C <= kReplayGraphMaxChains) {
+  if (replay && !ssq_new && host_mem(c) && n_iters == 1 && C <= kReplayGraphMaxChains) {
     Consts Kg = make_consts(c, (const double *)c->data.p);
     Kg.group_chains = c->group_chains;
     return run_replay_graph(c, Kg, A, z, u, g, tq, ts, ta);
@@ -417,6 +432,9 @@ int run_mcmc(rsf_ctx *c, int64_t n_iters, const double *z, const double *u, cons
   if ((rc = stage_in(c, 1, u, rows * sizeof(double), &du))) return rc;
   if ((rc = stage_in(c, 2, g, rows * sizeof(double), &dg))) return rc;
   A.z = (const double *)dz; A.u = (const double *)du; A.g = (const double *)dg;
+  const void *dsn = nullptr;
+  if ((rc = stage_in(c, 6, ssq_new, rows * sizeof(double), &dsn))) return rc;
+  A.ssq_new = (const double *)dsn;
   Consts K = make_consts(c, (const double *)c->data.p);
   K.group_chains = c->group_chains;
   if (host_mem(c) && !replay) {
@@ -428,7 +446,8 @@ int run_mcmc(rsf_ctx *c, int64_t n_iters, const double *z, const double *u, cons
   if ((rc = stage_out(c, 4, ts, rows * sizeof(double), &dts))) return rc;
   if ((rc = stage_out(c, 5, ta, rows, &dta))) return rc;
   A.tq = (double *)dtq; A.ts = (double *)dts; A.ta = (uint8_t *)dta;
-  rc = d == 1 ? launch_mcmc_d<1>(c, K, A, replay) : launch_mcmc_d<3>(c, K, A, replay);
+  if (ssq_new) rc = d == 1 ? launch_mcmc_inject<1>(c, K, A) : launch_mcmc_inject<3>(c, K, A);
+  else rc = d == 1 ? launch_mcmc_d<1>(c, K, A, replay) : launch_mcmc_d<3>(c, K, A, replay);
   if (rc) return rc;
   if ((rc = copy_back(c, 3, tq, rows * d * sizeof(double)))) return rc;
   if ((rc = copy_back(c, 4, ts, rows * sizeof(double)))) return rc;
@@ -494,8 +513,9 @@ const Rccl *rccl() {  // bound once, whichever thread asks first
 
 void free_chains(rsf_ctx *c) {
   release(c->data); release(c->q); release(c->ssq); release(c->std2); release(c->V);
-  release(c->wref); release(c->wsum); release(c->wsq); release(c->wn); release(c->stats);
+  release(c->wref); release(c->wsum); release(c->wsq); release(c->wn); release(c->wbuf); release(c->stats);
   c->have_chains = false;
+  c->external_chains = false;
 }
 
 }  // namespace
@@ -719,7 +739,13 @@ int rsf_mcmc_init(rsf_ctx *c, const rsf_mcmc_config *cfg, const double *q0, cons
   if ((rc = ensure(c->wsum, cb * d))) return rc;
   if ((rc = ensure(c->wsq, cb * d * d))) return rc;
   if ((rc = ensure(c->wn, (size_t)C * sizeof(int32_t)))) return rc;
-  if ((rc = ensure(c->stats, 3 * sizeof(unsigned long long)))) return rc;
+  if (cfg->adapt_mode == RSF_ADAPT_REFERENCE_DICT) {  // the window's samples themselves: np.cov's own arithmetic needs them
+    if (cfg->adapt_interval > RSF_DICT_MAX_INTERVAL)
+      return fail(RSF_ERR_UNSUPPORTED, "reference_dict adaptation keeps at most %d samples per window", RSF_DICT_MAX_INTERVAL);
+    if ((rc = ensure(c->wbuf, cb * (size_t)cfg->adapt_interval))) return rc;
+    HIP_TRY(hipMemsetAsync(c->wbuf.p, 0, cb * (size_t)cfg->adapt_interval, c->stream));
+  }
+  if ((rc = ensure(c->stats, RSF_CNT_COUNT * sizeof(unsigned long long)))) return rc;
   const hipMemcpyKind kind = host_mem(c) ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
   HIP_TRY(hipMemcpyAsync(c->data.p, data, data_bytes, kind, c->stream));
   const void *dq0;
@@ -729,7 +755,7 @@ int rsf_mcmc_init(rsf_ctx *c, const rsf_mcmc_config *cfg, const double *q0, cons
   HIP_TRY(hipMemsetAsync(c->wsum.p, 0, cb * d, c->stream));
   HIP_TRY(hipMemsetAsync(c->wsq.p, 0, cb * d * d, c->stream));
   HIP_TRY(hipMemsetAsync(c->wn.p, 0, (size_t)C * sizeof(int32_t), c->stream));
-  HIP_TRY(hipMemsetAsync(c->stats.p, 0, 3 * sizeof(unsigned long long), c->stream));
+  HIP_TRY(hipMemsetAsync(c->stats.p, 0, RSF_CNT_COUNT * sizeof(unsigned long long), c->stream));
   InitArgs A{};
   A.C = C;
   A.fd = cfg->fd_rel_step;
@@ -768,6 +794,7 @@ int rsf_mcmc_init(rsf_ctx *c, const rsf_mcmc_config *cfg, const double *q0, cons
   c->mc = *cfg;
   c->iters_done = 0;
   c->have_chains = true;
+  c->external_chains = false;
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipStreamSynchronize(c->stream));  // q0/data may be host buffers the caller reuses
   return RSF_OK;
@@ -814,13 +841,98 @@ int rsf_mcmc_set_state(rsf_ctx *c, const double *q, const double *ssq, const dou
 }
 
 int rsf_mcmc_run(rsf_ctx *c, int64_t n_iters, double *tq, double *ts, uint8_t *ta) {
-  return run_mcmc(c, n_iters, nullptr, nullptr, nullptr, tq, ts, ta, false);
+  return run_mcmc(c, n_iters, nullptr, nullptr, nullptr, nullptr, tq, ts, ta, false);
 }
 
 int rsf_mcmc_replay(rsf_ctx *c, int64_t n_iters, const double *z, const double *u, const double *g,
                     double *tq, double *ts, uint8_t *ta) {
   if (!z || !u || !g) return fail(RSF_ERR_INVALID, "rsf_mcmc_replay: z, u and g are required");
-  return run_mcmc(c, n_iters, z, u, g, tq, ts, ta, true);
+  return run_mcmc(c, n_iters, z, u, g, nullptr, tq, ts, ta, true);
+}
+
+int rsf_mcmc_replay_ssq(rsf_ctx *c, int64_t n_iters, const double *z, const double *u, const double *g, const double *ssq_new,
+                        double *tq, double *ts, uint8_t *ta) {
+  if (!z || !u || !g || !ssq_new) return fail(RSF_ERR_INVALID, "rsf_mcmc_replay_ssq: z, u, g and ssq_new are required");
+  return run_mcmc(c, n_iters, z, u, g, ssq_new, tq, ts, ta, true);
+}
+
+int rsf_mcmc_init_state(rsf_ctx *c, const rsf_mcmc_config *cfg, const double *q, const double *ssq, const double *std2, const double *V) {
+  if (!c || !cfg || !q || !ssq || !std2 || !V) return fail(RSF_ERR_INVALID, "rsf_mcmc_init_state: NULL argument");
+  if (cfg->size != sizeof(rsf_mcmc_config)) return fail(RSF_ERR_INVALID, "rsf_mcmc_init_state: struct size mismatch");
+  if (cfg->n_params != 1 && cfg->n_params != 3) return fail(RSF_ERR_UNSUPPORTED, "rsf_mcmc_init_state: n_params must be 1 or 3");
+  if (cfg->n_chains < 1) return fail(RSF_ERR_INVALID, "rsf_mcmc_init_state: n_chains < 1");
+  if (cfg->adapt_mode == RSF_ADAPT_REFERENCE_DICT && cfg->n_params != 1)
+    return fail(RSF_ERR_UNSUPPORTED, "rsf_mcmc_init_state: reference_dict adaptation is defined for 1 parameter only");
+  if (cfg->adapt_mode < 0 || cfg->adapt_mode > RSF_ADAPT_AM || (cfg->adapt_mode && cfg->adapt_interval < 2))
+    return fail(RSF_ERR_INVALID, "rsf_mcmc_init_state: bad adapt_mode / adapt_interval");
+  DeviceGuard guard(c->device);
+  if (!guard.ok) return fail(RSF_ERR_DEVICE, "rsf_mcmc_init_state: cannot select device %d", c->device);
+  const int d = cfg->n_params;
+  const int64_t C = cfg->n_chains;
+  const size_t cb = (size_t)C * sizeof(double);
+  int rc;
+  if ((rc = ensure(c->q, cb * d))) return rc;
+  if ((rc = ensure(c->ssq, cb))) return rc;
+  if ((rc = ensure(c->std2, cb))) return rc;
+  if ((rc = ensure(c->V, cb * d * d))) return rc;
+  if ((rc = ensure(c->wref, cb * d))) return rc;
+  if ((rc = ensure(c->wsum, cb * d))) return rc;
+  if ((rc = ensure(c->wsq, cb * d * d))) return rc;
+  if ((rc = ensure(c->wn, (size_t)C * sizeof(int32_t)))) return rc;
+  if (cfg->adapt_mode == RSF_ADAPT_REFERENCE_DICT) {  // the window's samples themselves: np.cov's own arithmetic needs them
+    if (cfg->adapt_interval > RSF_DICT_MAX_INTERVAL)
+      return fail(RSF_ERR_UNSUPPORTED, "reference_dict adaptation keeps at most %d samples per window", RSF_DICT_MAX_INTERVAL);
+    if ((rc = ensure(c->wbuf, cb * (size_t)cfg->adapt_interval))) return rc;
+    HIP_TRY(hipMemsetAsync(c->wbuf.p, 0, cb * (size_t)cfg->adapt_interval, c->stream));
+  }
+  if ((rc = ensure(c->stats, RSF_CNT_COUNT * sizeof(unsigned long long)))) return rc;
+  const hipMemcpyKind kind = host_mem(c) ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
+  const void *dq, *dV;
+  if ((rc = stage_in(c, 0, q, cb * d, &dq))) return rc;
+  if ((rc = stage_in(c, 1, V, cb * d * d, &dV))) return rc;
+  if ((rc = transpose(c, C, d, (const double *)dq, (double *)c->q.p, true))) return rc;
+  if ((rc = transpose(c, C, d * d, (const double *)dV, (double *)c->V.p, true))) return rc;
+  HIP_TRY(hipMemcpyAsync(c->ssq.p, ssq, cb, kind, c->stream));
+  HIP_TRY(hipMemcpyAsync(c->std2.p, std2, cb, kind, c->stream));
+  HIP_TRY(hipMemcpyAsync(c->wref.p, c->q.p, cb * d, hipMemcpyDeviceToDevice, c->stream));
+  HIP_TRY(hipMemsetAsync(c->wsum.p, 0, cb * d, c->stream));
+  HIP_TRY(hipMemsetAsync(c->wsq.p, 0, cb * d * d, c->stream));
+  HIP_TRY(hipMemsetAsync(c->wn.p, 0, (size_t)C * sizeof(int32_t), c->stream));
+  HIP_TRY(hipMemsetAsync(c->stats.p, 0, RSF_CNT_COUNT * sizeof(unsigned long long), c->stream));
+  c->mc = *cfg;
+  c->group_chains = 0;
+  c->iters_done = 0;
+  c->have_chains = true;
+  c->external_chains = true;
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(c->stream));  // the arguments may be host buffers the caller reuses
+  return RSF_OK;
+}
+
+int rsf_mcmc_propose(rsf_ctx *c, const double *z, double *q_new, uint8_t *in_bounds) {
+  if (!c || !z || !q_new || !in_bounds) return fail(RSF_ERR_INVALID, "rsf_mcmc_propose: NULL argument");
+  if (!c->have_chains) return fail(RSF_ERR_STATE, "rsf_mcmc_propose: call rsf_mcmc_init or rsf_mcmc_init_state first");
+  DeviceGuard guard(c->device);
+  if (!guard.ok) return fail(RSF_ERR_DEVICE, "rsf_mcmc_propose: cannot select device %d", c->device);
+  const int d = c->mc.n_params;
+  const int64_t C = c->mc.n_chains;
+  const size_t cb = (size_t)C * sizeof(double);
+  const void *dz;
+  void *dqn, *dinb;
+  int rc;
+  if ((rc = stage_in(c, 0, z, cb * d, &dz))) return rc;
+  if ((rc = stage_out(c, 3, q_new, cb * d, &dqn))) return rc;
+  if ((rc = stage_out(c, 5, in_bounds, (size_t)C, &dinb))) return rc;
+  ProposeArgs A{};
+  A.C = C; A.q = (const double *)c->q.p; A.V = (const double *)c->V.p; A.z = (const double *)dz;
+  for (int p = 0; p < RSF_MAX_PARAMS; ++p) { A.lo[p] = c->mc.lo[p]; A.hi[p] = c->mc.hi[p]; }
+  A.qn = (double *)dqn; A.inb = (uint8_t *)dinb;
+  const dim3 grid((unsigned)((C + kMaxBlock - 1) / kMaxBlock)), block(kMaxBlock);
+  if (d == 1) hipLaunchKernelGGL(propose_kernel<1>, grid, block, 0, c->stream, A);
+  else hipLaunchKernelGGL(propose_kernel<3>, grid, block, 0, c->stream, A);
+  if ((rc = copy_back(c, 3, q_new, cb * d))) return rc;
+  if ((rc = copy_back(c, 5, in_bounds, (size_t)C))) return rc;
+  return finish(c);
 }
 
 int rsf_mcmc_stats(rsf_ctx *c, int64_t *n_acc, int64_t *n_eval, int64_t *n_nonfinite, int64_t *n_done) {
@@ -830,10 +942,21 @@ int rsf_mcmc_stats(rsf_ctx *c, int64_t *n_acc, int64_t *n_eval, int64_t *n_nonfi
   unsigned long long s[3];
   HIP_TRY(hipMemcpyAsync(s, c->stats.p, sizeof s, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
-  if (n_acc) *n_acc = (int64_t)s[0];
-  if (n_eval) *n_eval = (int64_t)s[1];
-  if (n_nonfinite) *n_nonfinite = (int64_t)s[2];
+  if (n_acc) *n_acc = (int64_t)s[RSF_CNT_ACCEPTED];
+  if (n_eval) *n_eval = (int64_t)s[RSF_CNT_EVALUATED];
+  if (n_nonfinite) *n_nonfinite = (int64_t)s[RSF_CNT_NONFINITE];
   if (n_done) *n_done = c->iters_done;
+  return RSF_OK;
+}
+
+int rsf_mcmc_counters(rsf_ctx *c, int64_t *out, int32_t n) {
+  if (!c || !out || n < 0) return fail(RSF_ERR_INVALID, "rsf_mcmc_counters: bad argument");
+  if (!c->have_chains) return fail(RSF_ERR_STATE, "rsf_mcmc_counters: call rsf_mcmc_init first");
+  DeviceGuard guard(c->device);
+  unsigned long long s[RSF_CNT_COUNT];
+  HIP_TRY(hipMemcpyAsync(s, c->stats.p, sizeof s, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  for (int32_t k = 0; k < n && k < RSF_CNT_COUNT; ++k) out[k] = (int64_t)s[k];
   return RSF_OK;
 }
 
@@ -953,15 +1076,16 @@ int rsf_comm_init(rsf_ctx *c, int32_t world, int32_t rank, const uint8_t id[RSF_
 
 int rsf_comm_destroy(rsf_ctx *c) {
   if (!c) return fail(RSF_ERR_INVALID, "rsf_comm_destroy: NULL ctx");
-  if (c->comm) {
+  ncclComm_t comm = c->comm;
+  c->comm = nullptr;  // the ctx is out of its group whatever RCCL says about the teardown
+  c->world = 0;
+  c->rank = 0;
+  if (comm) {
     DeviceGuard guard(c->device);
     (void)hipStreamSynchronize(c->stream);
     const Rccl *R = rccl();
-    if (R) RCCL_TRY(R, R->comm_destroy(c->comm));
-    c->comm = nullptr;
+    if (R) RCCL_TRY(R, R->comm_destroy(comm));
   }
-  c->world = 0;
-  c->rank = 0;
   return RSF_OK;
 }
 
@@ -1125,6 +1249,8 @@ int rsf_mcmc_adapt(int32_t d, int32_t n, const double *window, int32_t adapt_mod
     return fail(RSF_ERR_INVALID, "rsf_mcmc_adapt: bad argument");
   if (adapt_mode == RSF_ADAPT_REFERENCE_DICT && d != 1)
     return fail(RSF_ERR_UNSUPPORTED, "rsf_mcmc_adapt: reference_dict adaptation is defined for 1 parameter only");
+  if (adapt_mode == RSF_ADAPT_REFERENCE_DICT && n > RSF_DICT_MAX_INTERVAL)
+    return fail(RSF_ERR_UNSUPPORTED, "rsf_mcmc_adapt: reference_dict windows hold at most %d samples", RSF_DICT_MAX_INTERVAL);
   double *dev = nullptr, h[10];
   const size_t wb = (size_t)n * d * sizeof(double);
   HIP_TRY(hipMalloc(&dev, wb + sizeof h));
@@ -1136,7 +1262,7 @@ int rsf_mcmc_adapt(int32_t d, int32_t n, const double *window, int32_t adapt_mod
   }
   (void)hipFree(dev);
   if (e != hipSuccess) return fail(RSF_ERR_DEVICE, "rsf_mcmc_adapt: %s", hipGetErrorString(e));
-  if (h[d * d] == 0.0) return fail(RSF_ERR_INVALID, "rsf_mcmc_adapt: the window's covariance is not positive definite");
+  if (h[d * d] == 0.0) return fail(RSF_ERR_NOT_POSDEF, "rsf_mcmc_adapt: the window's covariance is not positive definite");
   for (int i = 0; i < d * d; ++i) V_out[i] = h[i];
   return RSF_OK;
 }

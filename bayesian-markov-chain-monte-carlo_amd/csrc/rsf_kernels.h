@@ -39,10 +39,15 @@ constexpr int kMinBlocks = 2;
 // over 1 at 131 072 chains x nsteps 4000; the few spills it costs all lie outside the loops)
 constexpr int kD3Trip = 2;
 // LDS per workgroup for the loading table + observation chunk.  Two workgroups per CU (kMinBlocks) at 56 KiB each fit the
-// CU's 160 KiB next to the three-parameter samplers' per-lane slots (up to 24 KiB: Cholesky factors, parked chain state);
-// nsteps 2000 (48 KB) stays resident for the whole launch instead of being staged twice per proposal (+1.3 % at cfg2), and so
-// does nsteps 4000 of the float32 solve, whose tables are floats.
+// CU's 160 KiB next to the samplers' per-lane slots (up to 24 KiB: Cholesky factors, parked chain state); nsteps 2000
+// (48 KB) stays resident for the whole launch instead of being staged twice per proposal (+1.3 % at cfg2).  The chunk LENGTH
+// kc is sized once, for tables of doubles (rsf_set_model): the float32 sampler stages the same chunks as floats — half the
+// bytes, but nsteps 4000 is two chunks in that mode too, because its float64 init kernel shares the chunking.
 constexpr size_t kLdsBudget = 56 * 1024;
+// per-lane LDS slots (doubles) of the float64 RK4 sampler behind the table chunk: D = 3: the Cholesky factor's six; then the
+// chain's point, sigma^2, SSq and log u parked across the forward solve (mcmc_kernel)
+template <int D>
+constexpr int kParkSlots = (D == 3 ? 6 : 0) + D + 3;
 
 // ---------------------------------------------------------------------------------------------
 // kernels
@@ -70,7 +75,8 @@ forward_kernel(Consts K, int64_t n, const double *__restrict__ dc, const double 
       ssq = rsf::dp::solve<DAMP, WANT_SSQ, WANT_ACC>(lds, K, resident, active, dci, ai, bi, acc_i, n);
     } else {
       if (resident) rsf::stage_chunk(lds, K, 1, K.nout - 1);
-      ssq = rsf::solve<DAMP, WANT_SSQ, WANT_ACC, 2 * rsf::kTightUnroll>(lds, K, resident, active, dci, ai, bi, acc_i, n);
+      rsf::Wave W;  // every lane's result is wanted: no early rejection (thr = +inf), statistics unused
+      ssq = rsf::solve<DAMP, WANT_SSQ, WANT_ACC, 2 * rsf::kTightUnroll>(lds, K, resident, active, dci, ai, bi, INFINITY, acc_i, n, W);
     }
   }
   if (WANT_SSQ && active) ssq_out[i] = ssq;
@@ -322,6 +328,60 @@ __global__ void __launch_bounds__(kMaxBlock) ssq32_kernel(Consts K, int64_t C, c
   if (active) ssq[i] = s;
 }
 
+// The accept test of MCMC.py:327-331: log alpha = clip(0.5 (SSq_prev - SSq_new) / sigma^2, -inf, 0) > log u.  np.clip keeps a
+// NaN, and NaN > log u is False: a proposal whose series blew up (a stiff small-Dc lane under fixed-step RK4: Inf - Inf) is
+// REJECTED.  fmin(x, 0) would not do: IEEE minNum returns the operand that is not NaN, i.e. 0 > log u, accepted — which is
+// what this kernel did until round 4, unnoticed because no test before the wide-proposal ones produced a non-finite sum.
+__device__ __forceinline__ bool accept_test(double ratio, double log_u) {
+  const double logalpha = ratio > 0.0 ? 0.0 : ratio;  // NaN > 0 is false: NaN stays NaN
+  return logalpha > log_u;                             // NaN compares false => reject
+}
+
+// The proposal of MCMC.py:497 from the chain's point, the lower Cholesky factor of its proposal covariance (row-major
+// lower triangle, D (D + 1) / 2 entries) and D standard normals — one definition, so that rsf_mcmc_propose announces
+// exactly the point the sampler kernel will evaluate.
+template <int D, typename F>
+__device__ __forceinline__ void propose(const double (&q)[D], F factor, const double *z, double (&qn)[D]) {
+  int e = 0;
+#pragma unroll
+  for (int p = 0; p < D; ++p) {
+    double s = q[p];
+#pragma unroll
+    for (int r = 0; r <= p; ++r) s = __builtin_fma(factor(e++), z[r], s);
+    qn[p] = s;
+  }
+}
+
+template <int D>
+__device__ __forceinline__ bool in_box(const double (&qn)[D], const double *lo, const double *hi) {
+  bool inb = true;
+#pragma unroll
+  for (int p = 0; p < D; ++p) inb = inb && (qn[p] > lo[p]) && (qn[p] < hi[p]);  // strict box, MCMC.py:318-320
+  return inb;
+}
+
+// Per-wave statistics of a sampler launch: wave-uniform 32-bit accumulators (scalar registers), added to the ctx totals
+// (McmcArgs::stats, 64-bit) by the wave's first lane.  Index = RSF_CNT_* of rsf_abi.h.
+constexpr int kFlushEvery = 16;  // proposals between flushes: 16 x 4000 x 8 sub-steps x 64 lanes < 2^32
+struct WaveCounters {
+  uint32_t accepted, evaluated, nonfinite, oob, early, wave_solves, wave_skips;
+  rsf::Wave W;  // the running solve's control, and steps per tier / redone / lane_steps accumulated over the solves
+  __device__ __forceinline__ void reset() {
+    accepted = evaluated = nonfinite = oob = early = wave_solves = wave_skips = 0;
+    W.steps[0] = W.steps[1] = W.steps[2] = W.steps[3] = W.redone = W.lane_steps = 0;
+  }
+  __device__ __forceinline__ void flush(unsigned long long *stats) {
+    if ((threadIdx.x & 63) == 0) {
+      const uint32_t v[RSF_CNT_COUNT] = {accepted, evaluated, nonfinite, oob, early, wave_solves, wave_skips,
+                                         W.steps[0], W.steps[1], W.steps[2], W.steps[3], W.redone, W.lane_steps};
+#pragma unroll
+      for (int k = 0; k < RSF_CNT_COUNT; ++k)
+        if (v[k]) atomicAdd(&stats[k], (unsigned long long)v[k]);
+    }
+    reset();
+  }
+};
+
 struct McmcArgs {
   int64_t C, chain_offset, n_iters, iter_base;
   uint64_t seed;
@@ -334,15 +394,19 @@ struct McmcArgs {
   double *q, *ssq, *std2, *V;           // per-chain state: q[d][C], ssq[C], std2[C], V[d*d][C]
   double *wref, *wsum, *wsq;            // adaptation window (shifted sums): [d][C], [d][C], [d*d][C]
   int32_t *wn;
-  unsigned long long *stats;            // [3] accepted, evaluated, non-finite
+  double *wbuf;                         // reference_dict: the window's samples themselves, [adapt_interval][C] (rsf::np_cov_1d)
+  unsigned long long *stats;            // [RSF_CNT_COUNT] totals since rsf_mcmc_init (rsf_abi.h: rsf_mcmc_counters)
   const double *z, *u, *g;              // replay variates (REPLAY only): z[n][C][d], u[n][C], g[n][C]
+  const double *ssq_new;                // INJECT only: the proposals' sums of squares, [n][C] (rsf_mcmc_replay_ssq)
   double *tq, *ts;                      // traces, iteration-major: tq[n][C][d] (the ABI's layout), ts[n][C]
   uint8_t *ta;
 };
 
-template <int D, bool DAMP, bool REPLAY, int MODE>
+// INJECT (rsf_mcmc_replay_ssq): the proposals' sums of squares come from the caller — the chain logic alone, no tables, no solve.
+template <int D, bool DAMP, bool REPLAY, int MODE, bool INJECT = false>
 __global__ void __launch_bounds__(kMaxBlock, kMinBlocks) mcmc_kernel(Consts K, McmcArgs A) {
   static_assert(MODE == RK4_F64 || MODE == DOP853, "the float32 sampler is mcmc_f32x2_kernel (two chains per lane)");
+  static_assert(!INJECT || REPLAY, "supplied sums of squares come with supplied variates");
   extern __shared__ __attribute__((aligned(16))) double lds[];
   rsf::select_group(K);
   // Per-chain arrays are addressed as (wave-uniform row pointer)[threadIdx.x]: the row pointer — array + element * C + the
@@ -408,9 +472,12 @@ __global__ void __launch_bounds__(kMaxBlock, kMinBlocks) mcmc_kernel(Consts K, M
     at(A.wn, 0)[t] = wn;
   };
   if (kWinRegs && A.adapt_mode != RSF_ADAPT_NONE && valid) load_window(t);
-  uint32_t n_acc = 0, n_eval = 0, n_nonfinite = 0;
+  // statistics (rsf_mcmc_counters): wave-uniform popcounts and step counts — scalar registers, nothing per lane — added to
+  // the ctx totals by one lane every kFlushEvery proposals (32-bit accumulators cannot overflow in between)
+  WaveCounters cnt;
+  cnt.reset();
 
-  if (resident) {
+  if (resident && !INJECT) {
     if constexpr (MODE == DOP853) rsf::dp::stage_chunk_dp(lds, K, 1, K.nout - 1);
     else rsf::stage_chunk(lds, K, 1, K.nout - 1);
   }
@@ -439,51 +506,24 @@ __global__ void __launch_bounds__(kMaxBlock, kMinBlocks) mcmc_kernel(Consts K, M
       }
     }
     double qn[D];
-    bool inb = valid;
     if constexpr (D == 1) {
       double Lc;
       rsf::chol_lower<1>(&V1, &Lc);  // sqrt(V), or 0 where V is not positive
-      qn[0] = q[0] + Lc * z[0];
+      propose<1>(q, [&](int) { return Lc; }, z, qn);
     } else {
-      int e = 0;
-#pragma unroll
-      for (int p = 0; p < D; ++p) {
-        double s = q[p];
-#pragma unroll
-        for (int r = 0; r <= p; ++r) s += lcs[(e++) * blockDim.x] * z[r];
-        qn[p] = s;
-      }
+      propose<D>(q, [&](int e) { return lcs[e * blockDim.x]; }, z, qn);
     }
-#pragma unroll
-    for (int p = 0; p < D; ++p) inb = inb && (qn[p] > A.lo[p]) && (qn[p] < A.hi[p]);  // strict box, MCMC.py:318-320
-    // D = 3: the chain's current point, sigma^2 and SSq wait out the forward solve in LDS (five slots per lane behind the Cholesky
-    // factor) instead of in ten registers the integrator needs — the three spills per proposal this kernel had otherwise
-    constexpr bool kPark = D == 3 && MODE == RK4_F64;  // (the DOP853 kernel allocates worse with it: measured, tools/one_kernel.sh)
-    if constexpr (kPark) {
-#pragma unroll
-      for (int p = 0; p < D; ++p) lcs[(6 + p) * blockDim.x] = q[p];
-      lcs[9 * blockDim.x] = std2;
-      lcs[10 * blockDim.x] = ssq;
-    }
-    // ---- likelihood: forward solve only for in-bounds proposals, MCMC.py:322-324 ----
-    double an = K.a_def, bn = K.b_def;
-    if constexpr (D == 3) { an = qn[1]; bn = qn[2]; }
-    double ssqn = 0.0;
-    // (a wave with no in-bounds lane skips the solve when the tables are resident: no barrier inside)
-    if (!resident || __any(inb)) {
-      if constexpr (MODE == DOP853) ssqn = rsf::dp::solve<DAMP, true, false>(lds, K, resident, inb, qn[0], an, bn, nullptr, 0);
-      else ssqn = rsf::solve<DAMP, true, false, (D == 1 ? 2 : kD3Trip) * rsf::kTightUnroll>(lds, K, resident, inb, qn[0], an, bn, nullptr, 0);
-    }
-    if constexpr (kPark) {
-      const double *back = lcs;
-      asm volatile("" : "+v"(back));  // opaque: the values are re-read, not carried across the solve
-#pragma unroll
-      for (int p = 0; p < D; ++p) q[p] = back[(6 + p) * blockDim.x];
-      std2 = back[9 * blockDim.x];
-      ssq = back[10 * blockDim.x];
-    }
-    // ---- accept / reject, MCMC.py:327-333 ----
-    bool accept = false;
+    const bool inb = valid && in_box<D>(qn, A.lo, A.hi);
+    // The chain's current point, sigma^2, SSq and the logarithm of the accept test's uniform wait out the forward solve in LDS
+    // (per-lane slots behind the table chunk; D = 3: behind the Cholesky factor's six) instead of in registers the
+    // integrator needs — the spills per proposal these kernels had otherwise.
+    constexpr bool kPark = MODE == RK4_F64;  // (the DOP853 kernel allocates worse with it: measured, tools/one_kernel.sh)
+    constexpr int kSlotQ = D == 3 ? 6 : 0, kSlotStd2 = kSlotQ + D, kSlotSsq = kSlotStd2 + 1, kSlotLu = kSlotSsq + 1;
+    static_assert(kSlotLu + 1 == kParkSlots<D>, "rsf_hip.hip sizes the launch's LDS with kParkSlots");
+    // ---- the accept test's uniform, drawn before the solve: with it the largest sum of squares that could still be
+    // accepted is known, and a lane whose running sum passes it stops holding its wave (rsf::Wave).  thr is that bound
+    // widened by 1e-9 (rounding in the test itself is ~1e-16): a lane inside the margin simply integrates to the end.
+    double lu = 0.0, thr = INFINITY;
     if (inb) {
       double u;
       if (REPLAY) {
@@ -495,17 +535,60 @@ __global__ void __launch_bounds__(kMaxBlock, kMinBlocks) mcmc_kernel(Consts K, M
       }
       // (replaying recorded variates follows the reference's arithmetic to the last bit: IEEE division, libm-grade log;
       //  the sampler proper uses the kernel's own reciprocal and log — the same value to ~1 ulp)
-      const double logalpha = fmin(REPLAY ? 0.5 * (ssq - ssqn) / std2 : (0.5 * (ssq - ssqn)) * rsf::fm::rcp(std2), 0.0);
-      accept = logalpha > (REPLAY ? log(u) : rsf::rng_log(u));  // NaN compares false => reject
-      ++n_eval;
-      if (!isfinite(ssqn)) ++n_nonfinite;
+      lu = REPLAY ? log(u) : rsf::rng_log(u);
+      if constexpr (MODE == RK4_F64 && !INJECT) {
+        const double t0 = __builtin_fma(-2.0 * std2, lu, ssq);  // accept iff ssqn < ssq - 2 std2 log u, MCMC.py:327-331
+        thr = __builtin_fma(1e-9, __builtin_fabs(t0), t0);       // NaN (a chain whose state is not finite): never stops early
+      }
+    }
+    if constexpr (kPark) {
+#pragma unroll
+      for (int p = 0; p < D; ++p) lcs[(kSlotQ + p) * blockDim.x] = q[p];
+      lcs[kSlotStd2 * blockDim.x] = std2;
+      lcs[kSlotSsq * blockDim.x] = ssq;
+      lcs[kSlotLu * blockDim.x] = lu;
+    }
+    // ---- likelihood: forward solve only for in-bounds proposals, MCMC.py:322-324 ----
+    double an = K.a_def, bn = K.b_def;
+    if constexpr (D == 3) { an = qn[1]; bn = qn[2]; }
+    double ssqn = 0.0;
+    const unsigned long long inbmask = rsf::ballot(inb);
+    cnt.evaluated += (uint32_t)__builtin_popcountll(inbmask);
+    cnt.oob += (uint32_t)__builtin_popcountll(rsf::ballot(valid && !inb));
+    // (a wave with no in-bounds lane skips the solve when the tables are resident: no barrier inside)
+    if constexpr (INJECT) {
+      if (inb) ssqn = (A.ssq_new + row0)[tl];
+    } else if (!resident || inbmask != 0) {
+      if constexpr (MODE == DOP853) {
+        ssqn = rsf::dp::solve<DAMP, true, false>(lds, K, resident, inb, qn[0], an, bn, nullptr, 0);
+      } else {
+        ssqn = rsf::solve<DAMP, true, false, (D == 1 ? 2 : kD3Trip) * rsf::kTightUnroll>(lds, K, resident, inb, qn[0], an, bn, thr, nullptr, 0, cnt.W);
+        cnt.early += (uint32_t)__builtin_popcountll(inbmask & ~cnt.W.alive);
+      }
+    }
+    if (inbmask != 0) ++cnt.wave_solves;
+    else ++cnt.wave_skips;
+    if constexpr (kPark) {
+      const double *back = lcs;
+      asm volatile("" : "+v"(back));  // opaque: the values are re-read, not carried across the solve
+#pragma unroll
+      for (int p = 0; p < D; ++p) q[p] = back[(kSlotQ + p) * blockDim.x];
+      std2 = back[kSlotStd2 * blockDim.x];
+      ssq = back[kSlotSsq * blockDim.x];
+      lu = back[kSlotLu * blockDim.x];
+    }
+    // ---- accept / reject, MCMC.py:327-333 ----
+    bool accept = false;
+    if (inb) {
+      accept = accept_test(REPLAY ? 0.5 * (ssq - ssqn) / std2 : (0.5 * (ssq - ssqn)) * rsf::fm::rcp(std2), lu);
       if (accept) {
         ssq = ssqn;
 #pragma unroll
         for (int p = 0; p < D; ++p) q[p] = qn[p];
-        ++n_acc;
       }
     }
+    cnt.accepted += (uint32_t)__builtin_popcountll(rsf::ballot(accept));
+    cnt.nonfinite += (uint32_t)__builtin_popcountll(rsf::ballot(inb && !isfinite(ssqn)));
     // ---- sigma^2 Gibbs update with the post-accept SSq, MCMC.py:158-160 ----
     if (valid) {
       const double bval = 0.5 * (A.n0 * std2 + ssq);
@@ -528,14 +611,17 @@ __global__ void __launch_bounds__(kMaxBlock, kMinBlocks) mcmc_kernel(Consts K, M
         for (int r = 0; r < D; ++r) wq[p * D + r] += (q[p] - wr[p]) * (q[r] - wr[r]);
       }
       ++wn;
+      if (A.adapt_mode == RSF_ADAPT_REFERENCE_DICT) at(A.wbuf, (int)((A.iter_base + n) % A.adapt_interval))[tl] = q[0];
       if ((A.iter_base + n + 1) % A.adapt_interval == 0) {
         if (wn >= 2) {
           const double nn = (double)wn;
           double Vn[D * D], Ln[D * D];
           if (A.adapt_mode == RSF_ADAPT_REFERENCE_DICT) {
             // d := len(qpriors.keys()) (2 for {1: lo, 2: hi}), and the Cholesky FACTOR becomes the next covariance
-            // (one-parameter chains only: rsf_mcmc_init refuses the mode for D = 3)
-            if (rsf::window_covariance<1>(ws, wq, nn, A.dict_scale, Vn, Ln)) V1 = Ln[0];
+            // (one-parameter chains only: rsf_mcmc_init refuses the mode for D = 3).  The window's covariance in np.cov's own
+            // arithmetic, from the samples kept in wbuf (full and in order whenever an adaptation is due).
+            Vn[0] = A.dict_scale * rsf::np_cov_1d([&](int k) { return at(A.wbuf, k)[tl]; }, A.adapt_interval);
+            if (rsf::chol_lower<1>(Vn, Ln)) V1 = Ln[0];
           } else if (rsf::window_covariance<D>(ws, wq, nn, 2.38 * 2.38 / (double)D, Vn, Ln)) {
             if constexpr (D == 1) {
               V1 = Vn[0];
@@ -554,6 +640,7 @@ __global__ void __launch_bounds__(kMaxBlock, kMinBlocks) mcmc_kernel(Consts K, M
       }
       if (!kWinRegs) store_window(tl);
     }
+    if ((n & (kFlushEvery - 1)) == kFlushEvery - 1) cnt.flush(A.stats);
   }
 
   if (valid) {
@@ -564,13 +651,39 @@ __global__ void __launch_bounds__(kMaxBlock, kMinBlocks) mcmc_kernel(Consts K, M
     at(A.std2, 0)[t] = std2;
     if (kWinRegs && A.adapt_mode != RSF_ADAPT_NONE) store_window(t);
   }
-  // statistics: wave shuffle reduction, one atomic per wave and counter
-  const unsigned long long s0 = rsf::wave_sum(n_acc), s1 = rsf::wave_sum(n_eval), s2 = rsf::wave_sum(n_nonfinite);
-  if ((threadIdx.x & 63) == 0) {
-    if (s0) atomicAdd(&A.stats[0], s0);
-    if (s1) atomicAdd(&A.stats[1], s1);
-    if (s2) atomicAdd(&A.stats[2], s2);
-  }
+  cnt.flush(A.stats);
+}
+
+// rsf_mcmc_propose: the proposal the next iteration of mcmc_kernel will make from z, and whether it is inside the box
+struct ProposeArgs {
+  int64_t C;
+  const double *q, *V;  // [d][C], [d*d][C]
+  const double *z;      // [C][d]
+  double lo[RSF_MAX_PARAMS], hi[RSF_MAX_PARAMS];
+  double *qn;           // [C][d]
+  uint8_t *inb;         // [C]
+};
+
+template <int D>
+__global__ void __launch_bounds__(kMaxBlock) propose_kernel(ProposeArgs A) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= A.C) return;
+  double q[D], V[D * D], Lf[D * D], z[D], qn[D];
+#pragma unroll
+  for (int p = 0; p < D; ++p) { q[p] = A.q[p * A.C + i]; z[p] = A.z[i * D + p]; }
+#pragma unroll
+  for (int e = 0; e < D * D; ++e) V[e] = A.V[e * A.C + i];
+  rsf::chol_lower<D>(V, Lf);
+  double tri[D * (D + 1) / 2];
+  int e = 0;
+#pragma unroll
+  for (int p = 0; p < D; ++p)
+#pragma unroll
+    for (int r = 0; r <= p; ++r) tri[e++] = Lf[p * D + r];
+  propose<D>(q, [&](int k) { return tri[k]; }, z, qn);
+#pragma unroll
+  for (int p = 0; p < D; ++p) A.qn[i * D + p] = qn[p];
+  A.inb[i] = in_box<D>(qn, A.lo, A.hi) ? 1 : 0;
 }
 
 // The float32 sampler (RSF_FLAG_FP32_SOLVE): the same iteration as mcmc_kernel, with TWO chains per lane, because its
@@ -660,7 +773,7 @@ __global__ void __launch_bounds__(kMaxBlock, kMinBlocks) mcmc_f32x2_kernel(Const
     }
     if (kWinRegs && A.adapt_mode != RSF_ADAPT_NONE && c.valid) load_window(s, t);
   }
-  uint32_t n_acc = 0, n_eval = 0, n_nonfinite = 0;
+  uint32_t n_acc = 0, n_eval = 0, n_nonfinite = 0, n_oob = 0;  // (the tier / wave counters belong to the float64 RK4 step)
 
   float *lds32 = reinterpret_cast<float *>(lds);
   if (resident) rsf::f32::stage_chunk32(lds32, K, 1, K.nout - 1);
@@ -710,6 +823,7 @@ __global__ void __launch_bounds__(kMaxBlock, kMinBlocks) mcmc_f32x2_kernel(Const
       inb[s] = c.valid;
 #pragma unroll
       for (int p = 0; p < D; ++p) inb[s] = inb[s] && (qn[s][p] > A.lo[p]) && (qn[s][p] < A.hi[p]);  // strict box, MCMC.py:318-320
+      if (c.valid && !inb[s]) ++n_oob;
       ssqn[s] = 0.0;
     }
     // ---- likelihood: forward solve only for in-bounds proposals, MCMC.py:322-324 ----
@@ -737,8 +851,8 @@ __global__ void __launch_bounds__(kMaxBlock, kMinBlocks) mcmc_f32x2_kernel(Const
         }
         // (replaying recorded variates follows the reference's arithmetic to the last bit: IEEE division, libm-grade log;
         //  the sampler proper uses the kernel's own reciprocal and log — the same value to ~1 ulp)
-        const double logalpha = fmin(REPLAY ? 0.5 * (c.ssq - ssqn[s]) / c.std2 : (0.5 * (c.ssq - ssqn[s])) * rsf::fm::rcp(c.std2), 0.0);
-        accept = logalpha > (REPLAY ? log(u) : rsf::rng_log(u));  // NaN compares false => reject
+        accept = accept_test(REPLAY ? 0.5 * (c.ssq - ssqn[s]) / c.std2 : (0.5 * (c.ssq - ssqn[s])) * rsf::fm::rcp(c.std2),
+                             REPLAY ? log(u) : rsf::rng_log(u));
         ++n_eval;
         if (!isfinite(ssqn[s])) ++n_nonfinite;
         if (accept) {
@@ -770,14 +884,16 @@ __global__ void __launch_bounds__(kMaxBlock, kMinBlocks) mcmc_f32x2_kernel(Const
           for (int r = 0; r < D; ++r) c.wq[p * D + r] += (c.q[p] - c.wr[p]) * (c.q[r] - c.wr[r]);
         }
         ++c.wn;
+        if (A.adapt_mode == RSF_ADAPT_REFERENCE_DICT) at(A.wbuf, (int)((A.iter_base + n) % A.adapt_interval), s)[tl] = c.q[0];
         if ((A.iter_base + n + 1) % A.adapt_interval == 0) {
           if (c.wn >= 2) {
             const double nn = (double)c.wn;
             double Vn[D * D], Ln[D * D];
             if (A.adapt_mode == RSF_ADAPT_REFERENCE_DICT) {
               // d := len(qpriors.keys()) (2 for {1: lo, 2: hi}), and the Cholesky FACTOR becomes the next covariance
-              // (one-parameter chains only: rsf_mcmc_init refuses the mode for D = 3)
-              if (rsf::window_covariance<1>(c.ws, c.wq, nn, A.dict_scale, Vn, Ln)) c.V1 = Ln[0];
+              // (one-parameter chains only: rsf_mcmc_init refuses the mode for D = 3); np.cov's own arithmetic (mcmc_kernel)
+              Vn[0] = A.dict_scale * rsf::np_cov_1d([&](int k) { return at(A.wbuf, k, s)[tl]; }, A.adapt_interval);
+              if (rsf::chol_lower<1>(Vn, Ln)) c.V1 = Ln[0];
             } else if (rsf::window_covariance<D>(c.ws, c.wq, nn, 2.38 * 2.38 / (double)D, Vn, Ln)) {
               if constexpr (D == 1) {
                 c.V1 = Vn[0];
@@ -812,11 +928,12 @@ __global__ void __launch_bounds__(kMaxBlock, kMinBlocks) mcmc_f32x2_kernel(Const
     }
   }
   // statistics: wave shuffle reduction, one atomic per wave and counter
-  const unsigned long long s0 = rsf::wave_sum(n_acc), s1 = rsf::wave_sum(n_eval), s2 = rsf::wave_sum(n_nonfinite);
+  const unsigned long long s0 = rsf::wave_sum(n_acc), s1 = rsf::wave_sum(n_eval), s2 = rsf::wave_sum(n_nonfinite), s3 = rsf::wave_sum(n_oob);
   if ((threadIdx.x & 63) == 0) {
-    if (s0) atomicAdd(&A.stats[0], s0);
-    if (s1) atomicAdd(&A.stats[1], s1);
-    if (s2) atomicAdd(&A.stats[2], s2);
+    if (s0) atomicAdd(&A.stats[RSF_CNT_ACCEPTED], s0);
+    if (s1) atomicAdd(&A.stats[RSF_CNT_EVALUATED], s1);
+    if (s2) atomicAdd(&A.stats[RSF_CNT_NONFINITE], s2);
+    if (s3) atomicAdd(&A.stats[RSF_CNT_OUT_OF_BOUNDS], s3);
   }
 }
 
@@ -839,7 +956,13 @@ __device__ void adapt_window(int n, const double *win, int mode, double dict_sca
       for (int r = 0; r < D; ++r) wq[p * D + r] += (win[k * D + p] - win[p]) * (win[k * D + r] - win[r]);
     }
   const bool dict = mode == RSF_ADAPT_REFERENCE_DICT;
-  const bool ok = n >= 2 && rsf::window_covariance<D>(ws, wq, (double)n, dict ? dict_scale : 2.38 * 2.38 / (double)D, Vn, Ln);
+  bool ok = n >= 2;
+  if (dict) {  // one parameter: np.cov's own arithmetic, like the sampler's
+    Vn[0] = ok ? dict_scale * rsf::np_cov_1d([&](int k) { return win[k * D]; }, n) : 0.0;
+    ok = ok && rsf::chol_lower<1>(Vn, Ln);
+  } else {
+    ok = ok && rsf::window_covariance<D>(ws, wq, (double)n, 2.38 * 2.38 / (double)D, Vn, Ln);
+  }
 #pragma unroll
   for (int e = 0; e < D * D; ++e) out[e] = dict ? Ln[e] : Vn[e];
   out[D * D] = ok ? 1.0 : 0.0;

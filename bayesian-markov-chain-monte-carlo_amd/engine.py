@@ -182,6 +182,12 @@ class Engine:
             raise ValueError(f"data has {int(data.shape[-1])} entries per series, the model produces {self.nout}")
         if C % n_groups:
             raise ValueError(f"{C} chains cannot be split evenly over {n_groups} observation groups")
+        cfg = self._mcmc_config(C, d, lo, hi, seed, chain_offset, n0, prior_len, adapt_mode, adapt_interval, fd_rel_step, n_groups)
+        _abi.check(self.lib, self.lib.rsf_mcmc_init(self._ctx, ctypes.byref(cfg), self._ptr(q0), self._ptr(data)))
+        self.n_chains, self.n_params = C, d
+
+    def _mcmc_config(self, C, d, lo, hi, seed=0, chain_offset=0, n0=0.01, prior_len=0, adapt_mode="none", adapt_interval=10,
+                     fd_rel_step=1e-6, n_groups=1):
         lo, hi = np.broadcast_to(np.asarray(lo, dtype=np.float64), (d,)), np.broadcast_to(np.asarray(hi, dtype=np.float64), (d,))
         cfg = _abi.McmcConfig()
         cfg.size = ctypes.sizeof(_abi.McmcConfig)
@@ -191,8 +197,42 @@ class Engine:
         cfg.adapt_interval, cfg.fd_rel_step, cfg.n_groups = int(adapt_interval), float(fd_rel_step), n_groups
         for p in range(d):
             cfg.lo[p], cfg.hi[p] = float(lo[p]), float(hi[p])
-        _abi.check(self.lib, self.lib.rsf_mcmc_init(self._ctx, ctypes.byref(cfg), self._ptr(q0), self._ptr(data)))
+        return cfg
+
+    def mcmc_init_state(self, q, ssq, std2, V, lo, hi, **kw):
+        """Chains from an explicit state (rsf_mcmc_init_state): no model, no observation — the sampler as an operator over
+        a likelihood the caller evaluates; advanced by mcmc_replay_ssq only.  q (C, d), ssq (C,), std2 (C,), V (C, d, d)."""
+        q = self._in(q)
+        if q.ndim == 1:
+            q = q.reshape(-1, 1)
+        C, d = int(q.shape[0]), int(q.shape[1])
+        ssq, std2, V = self._in(ssq), self._in(std2), self._in(V)
+        if int(np.prod(ssq.shape)) != C or int(np.prod(std2.shape)) != C or int(np.prod(V.shape)) != C * d * d:
+            raise ValueError("ssq and std2 hold one value per chain, V one (d, d) matrix per chain")
+        cfg = self._mcmc_config(C, d, lo, hi, **kw)
+        _abi.check(self.lib, self.lib.rsf_mcmc_init_state(self._ctx, ctypes.byref(cfg), self._ptr(q), self._ptr(ssq), self._ptr(std2),
+                                                          self._ptr(V)))
         self.n_chains, self.n_params = C, d
+
+    def mcmc_propose(self, z):
+        """The proposals the next iteration will make from the normals z (C, d) → (q_new (C, d), in_bounds (C,) uint8)."""
+        self._need_chains()
+        C, d = self.n_chains, self.n_params
+        z = self._in(z)
+        if int(np.prod(z.shape)) != C * d:
+            raise ValueError(f"z must hold {d} normals for each of the {C} chains")
+        qn, inb = self._empty((C, d)), self._empty((C,), np.uint8)
+        _abi.check(self.lib, self.lib.rsf_mcmc_propose(self._ctx, self._ptr(z), self._ptr(qn), self._ptr(inb)))
+        return qn, inb
+
+    def mcmc_replay_ssq(self, z, u, g, ssq_new, traces=True):
+        """mcmc_replay with the proposals' sums of squares supplied by the caller (n, C): the chain logic alone."""
+        z, u, g, ssq_new = self._in(z), self._in(u), self._in(g), self._in(ssq_new)
+        n_iters = int(u.shape[0])
+        tq, ts, ta = self._traces(n_iters, traces)
+        _abi.check(self.lib, self.lib.rsf_mcmc_replay_ssq(self._ctx, n_iters, self._ptr(z), self._ptr(u), self._ptr(g), self._ptr(ssq_new),
+                                                          self._ptr(tq), self._ptr(ts), self._ptr(ta)))
+        return tq, ts, ta
 
     def get_state(self):
         self._need_chains()
@@ -234,6 +274,16 @@ class Engine:
         v = [ctypes.c_int64() for _ in range(4)]
         _abi.check(self.lib, self.lib.rsf_mcmc_stats(self._ctx, *[ctypes.byref(x) for x in v]))
         return dict(zip(("accepted", "evaluated", "nonfinite", "iters_done"), (x.value for x in v)))
+
+    def counters(self):
+        """rsf_mcmc_counters → dict: the chain totals plus, on the HIP library, how the float64 RK4 kernels spent their
+        wave-steps (tier by tier, redone trips, lane utilisation); `lane_utilisation` is derived."""
+        v = (ctypes.c_int64 * len(_abi.COUNTERS))()
+        _abi.check(self.lib, self.lib.rsf_mcmc_counters(self._ctx, v, len(_abi.COUNTERS)))
+        c = dict(zip(_abi.COUNTERS, (int(x) for x in v)))
+        steps = c["steps_tight"] + c["steps_narrow"] + c["steps_wide"] + c["steps_full"]
+        c["lane_utilisation"] = c["lane_steps"] / (64.0 * steps) if steps else None
+        return c
 
     # -- posterior post-processing (RSF.plot_dist, RSF.py:717-746) -------------------------
     def _column(self, samples, param):

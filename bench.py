@@ -146,6 +146,92 @@ def reference_scheme_rate(model, data, C, nsteps, proposals=5):
             "unit": "ODE-steps*chains/s", "sample": f"{C} chains x {proposals} proposals x nsteps {nsteps}"}
 
 
+SWEEP = dict(dc_list=[100.0, 1325.0, 2550.0, 3775.0, 5000.0], qstart=1000.0, lo=0.0, hi=1.0e4, nsteps=500,
+             chains_per_group=65536, burn=300, ips=100, launches=3)
+
+
+def main_py_sweep(pkg, lib=None, chains_per_group=None, burn=None, ips=None, launches=None, headline_rate=None):
+    """The reference's OWN problem shape (main.py:50-56): dc_list = linspace(100, 5000, 5), every chain started at
+    QSTART = 1000, the LIST prior ["Uniform", 0, 10000] — with which the reference never adapts its proposal (the
+    AttributeError of MCMC.py:200 is swallowed at MCMC.py:524-527), so the proposal keeps the width of Vstart — nsteps 500.
+    One observation series per true Dc, one group of chains per series (RSF.inference_batched's shape).  This is the
+    data-dependent BAD case of the sampler kernel, next to the headline's good one: at Dc_true = 100 about four proposals
+    in ten fall outside the box (idle lanes, MCMC.py:318-322), the rest spread over every integration tier down to stiff
+    small-Dc ones, and almost all of them are rejected.  Timed: the whole sweep as ONE launch per step, and every group
+    alone (same chains: the RNG is keyed by the global chain id), each after `burn` untimed proposals; the counters
+    (rsf_mcmc_counters) say where the wave-steps went.  `per_evaluated_step_vs_headline`: the group's rate per RK4 step of an
+    IN-BOUNDS proposal over the headline's (all in bounds, all TIGHT)."""
+    import torch
+
+    cg = chains_per_group or SWEEP["chains_per_group"]
+    burn = SWEEP["burn"] if burn is None else burn
+    ips, launches = ips or SWEEP["ips"], launches or SWEEP["launches"]
+    nsteps, dcs = SWEEP["nsteps"], SWEEP["dc_list"]
+    G = len(dcs)
+    model = pkg.RateStateModel(number_time_steps=nsteps)
+    mk = (lambda **kw: pkg.Engine(lib=lib, **kw)) if lib is not None else (lambda **kw: pkg.Engine(**kw))
+    with mk(mem="host") as e:
+        e.set_model(model, 1)
+        _, acc = e.forward(dcs)  # (nout, G): the clean series of every true Dc (RSF.generate_time_series, RSF.py:355-371)
+    rng = np.random.default_rng(2025)
+    data = np.stack([acc[:, g] + np.abs(acc[:, g]) * rng.standard_normal(acc.shape[0]) for g in range(G)])
+
+    def run(first_group, n_groups):
+        C = cg * n_groups
+        eng = mk(mem="device")
+        eng.set_model(model, 1)
+        q0 = torch.full((C, 1), SWEEP["qstart"], dtype=torch.float64, device="cuda")
+        d = torch.as_tensor(data[first_group:first_group + n_groups] if n_groups > 1 else data[first_group], device="cuda")
+        eng.mcmc_init(q0, d, [SWEEP["lo"]], [SWEEP["hi"]], seed=2025, chain_offset=first_group * cg, prior_len=3, adapt_mode="none")
+        tr = (torch.empty((ips, C, 1), dtype=torch.float64, device="cuda"), torch.empty((ips, C), dtype=torch.float64, device="cuda"), None)
+        done = 0
+        while done < burn:  # untimed: lets the chains leave the common start (the trace rows are overwritten)
+            n = min(ips, burn - done)
+            eng.mcmc_run(n, out=tuple(t[:n] if t is not None else None for t in tr))
+            done += n
+        torch.cuda.synchronize()
+        has_counters = hasattr(eng.lib, "rsf_mcmc_counters")
+        c0, s0 = (eng.counters() if has_counters else None), eng.stats()
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(launches)]
+        for a, b in ev:
+            a.record()
+            eng.mcmc_run(ips, out=tr)
+            b.record()
+        torch.cuda.synchronize()
+        ms = float(np.median([a.elapsed_time(b) for a, b in ev]))
+        c1, s1 = (eng.counters() if has_counters else None), eng.stats()
+        props = C * ips * launches
+        evaluated = (s1["evaluated"] - s0["evaluated"]) / props
+        out = {"chains": C, "ms_per_launch": ms, "value": C * ips * nsteps / (ms * 1e-3), "evaluated_fraction": evaluated,
+               "acceptance": (s1["accepted"] - s0["accepted"]) / props,
+               "posterior_mean": float(tr[0][:, :, 0].mean()), "proposal_std": float(eng.get_state()[3].flatten().sqrt().mean())}
+        out["per_evaluated_step"] = out["value"] * evaluated
+        if headline_rate:
+            out["per_evaluated_step_vs_headline"] = out["per_evaluated_step"] / headline_rate
+        if has_counters:
+            dlt = {k: c1[k] - c0[k] for k in c0 if k != "lane_utilisation"}
+            steps = dlt["steps_tight"] + dlt["steps_narrow"] + dlt["steps_wide"] + dlt["steps_full"]
+            waves = dlt["wave_solves"] + dlt["wave_skips"]
+            out["counters"] = {
+                "out_of_bounds_fraction": dlt["out_of_bounds"] / props, "early_rejected_of_evaluated": dlt["early_rejected"] / max(1, dlt["evaluated"]),
+                "wave_skip_fraction": dlt["wave_skips"] / max(1, waves),
+                "wave_steps_vs_full_series": steps / max(1, dlt["wave_solves"] * (nsteps - 1)),
+                "tier_share": {t: dlt["steps_" + t] / max(1, steps) for t in ("tight", "narrow", "wide", "full")},
+                "redone_share": dlt["steps_redone"] / max(1, steps), "lane_utilisation": dlt["lane_steps"] / max(1, 64 * steps)}
+        eng.close()
+        del tr
+        torch.cuda.empty_cache()
+        return out
+
+    res = {"workload": f"main.py sweep: dc_list {dcs}, qstart {SWEEP['qstart']}, list prior ({SWEEP['lo']}, {SWEEP['hi']}) (no adaptation), "
+                       f"nsteps {nsteps}, {cg} chains per group, {burn} untimed + {launches} x {ips} timed proposals per chain",
+           "unit": "ODE-steps*chains/s (nominal: chains x proposals x nsteps / s)", "headline_rate_used": headline_rate,
+           "all_groups_one_launch": run(0, G), "groups": {}}
+    for g, dc in enumerate(dcs):
+        res["groups"][f"dc_true_{dc:g}"] = run(g, 1)
+    return res
+
+
 def abi_pool_allgather(eng, local, expected_pool, rdist, timeout_s=90.0):
     """The same posterior-pool exchange through the C ABI (rsf_comm_init + rsf_pool_allgather: the library's own
     RCCL communicator on the engine's stream), checked against the torch.distributed pool.  Outside the timed
@@ -314,6 +400,7 @@ def main():
     ap.add_argument("--iters-per-step", type=int, default=100, help="proposals per chain per launch (SURVEY §8d: 100)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-also", action="store_true", help="skip the secondary configs[1] measurement")
+    ap.add_argument("--no-sweep", action="store_true", help="skip also.main_py_sweep (the reference's own dc_list / list-prior problem)")
     ap.add_argument("--integrator", default="rk4", choices=["rk4", "dop853"],
                     help="dop853 = the reference's own adaptive scheme (side measurement / profiling; the metric is quoted on rk4)")
     ap.add_argument("--precision", default="float64", choices=["float64", "float32"], help="float32 = config-5 tolerance-sweep solve")
@@ -428,6 +515,10 @@ def main():
             eng_o.close()
             del tr_o
             torch.cuda.empty_cache()
+            if not args.no_sweep:
+                # the data-dependent bad case next to the headline's good one: the reference's own main.py problem
+                cfg1_rate = out["also"]["cfg1"]["value"] if "cfg1" in out["also"] else value
+                out["also"]["main_py_sweep"] = main_py_sweep(pkg, headline_rate=cfg1_rate)
         if not args.no_cpu_baseline and d == 1 and mode == "RK4":
             out["reference_scheme"] = reference_scheme_rate(model, data, C, nsteps)
             out["cpu_baseline"] = cpu_baseline(model, data)

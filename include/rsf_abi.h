@@ -53,6 +53,7 @@ extern "C" {
 #define RSF_ERR_STATE (-3)       /* call order (model or chains not initialised) */
 #define RSF_ERR_NOMEM (-4)
 #define RSF_ERR_UNSUPPORTED (-5)
+#define RSF_ERR_NOT_POSDEF (-6)  /* rsf_mcmc_adapt: the window's covariance has no Cholesky factor (np.linalg.LinAlgError) */
 
 /* where caller buffers live */
 #define RSF_MEM_HOST 0
@@ -68,10 +69,13 @@ extern "C" {
 
 /* rsf_mcmc_config.adapt_mode (MCMC.py:162-204, 523-527) */
 #define RSF_ADAPT_NONE 0           /* list prior: adaptation raises and is swallowed => never adapts */
-#define RSF_ADAPT_REFERENCE_DICT 1 /* dict prior: V <- chol(2.38^2/prior_len * cov(window)), then used AS covariance */
+#define RSF_ADAPT_REFERENCE_DICT 1 /* dict prior: V <- chol(2.38^2/prior_len * np.cov(window)), then used AS covariance; np.cov in
+                                      NumPy's own arithmetic (pairwise-summed mean), so that a window of identical samples
+                                      fails or "succeeds" with a collapsed proposal exactly where the reference's does */
 #define RSF_ADAPT_AM 2             /* corrected adaptive Metropolis: V <- 2.38^2/d * cov(window) */
 
 #define RSF_MAX_PARAMS 3
+#define RSF_DICT_MAX_INTERVAL 128 /* reference_dict adaptation keeps its window's samples: adapt_interval at most this (default 10) */
 
 typedef struct rsf_ctx rsf_ctx;
 
@@ -195,6 +199,53 @@ int rsf_mcmc_replay(rsf_ctx *ctx, int64_t n_iters, const double *z, const double
 int rsf_mcmc_stats(rsf_ctx *ctx, int64_t *n_accepted, int64_t *n_evaluated, int64_t *n_nonfinite,
                    int64_t *n_iters_done);
 
+/* Launch statistics since rsf_mcmc_init, summed over this ctx's chains: out[k] for k < min(n, RSF_CNT_COUNT).
+ * The first five are properties of the chains and identical in both libraries; the rest describe how the HIP kernels spent
+ * their wave-steps (a wave = 64 chains advancing in lockstep) and are zero in the checker, which has no waves.  They
+ * exist so that a data-dependent slowdown is measured, not inferred: wide proposal distributions (the reference's own
+ * main.py: list prior, no adaptation, MCMC.py:524-527) leave lanes idle on out-of-bounds proposals (MCMC.py:318-322) and
+ * put stiff small-Dc proposals next to ordinary ones. */
+#define RSF_CNT_ACCEPTED 0       /* accepted proposals */
+#define RSF_CNT_EVALUATED 1      /* proposals inside the prior box (each costs a forward solve, MCMC.py:322-324) */
+#define RSF_CNT_NONFINITE 2      /* in-bounds proposals whose sum of squares was NaN/Inf when their solve ended */
+#define RSF_CNT_OUT_OF_BOUNDS 3  /* proposals outside the box: rejected without a solve */
+#define RSF_CNT_EARLY_REJECTED 4 /* HIP, float64 RK4: in-bounds proposals whose solve stopped before the end of the series
+                                    because the running sum of squares already exceeded what this iteration's uniform
+                                    could accept (partial sums of squares only grow; the decision is the one the full
+                                    series would give).  0 in the checker, which always integrates to the end. */
+#define RSF_CNT_WAVE_SOLVES 5    /* wave-proposals with at least one in-bounds lane (a forward solve was started) */
+#define RSF_CNT_WAVE_SKIPS 6     /* wave-proposals with no in-bounds lane (no solve) */
+#define RSF_CNT_STEPS_TIGHT 7    /* wave-steps (RK4 steps of one wave) integrated in each tier of the float64 RK4 step: */
+#define RSF_CNT_STEPS_NARROW 8   /*   TIGHT / NARROW / WIDE = incremental evaluation with series of growing length,     */
+#define RSF_CNT_STEPS_WIDE 9     /*   FULL = log / exp / reciprocal at every stage (stiff small-Dc lanes)                */
+#define RSF_CNT_STEPS_FULL 10
+#define RSF_CNT_STEPS_REDONE 11  /* wave-steps of incremental trips thrown away because a lane left the tier's guard region */
+#define RSF_CNT_LANE_STEPS 12    /* sum over wave-steps of the lanes still integrating: lane utilisation =
+                                    LANE_STEPS / (64 * (STEPS_TIGHT + STEPS_NARROW + STEPS_WIDE + STEPS_FULL)) */
+#define RSF_CNT_COUNT 13
+int rsf_mcmc_counters(rsf_ctx *ctx, int64_t *out, int32_t n);
+
+/* ---- the sampler as an operator over a caller-evaluated likelihood ------------------------------------------
+ * The reference's sampler takes ANY model object with a settable .Dc and .evaluate() (MCMC.py:65-66, 127, 381-384).  These
+ * three calls run its chain logic — proposal, strict box test, accept test, sigma^2 update, adaptation; MCMC.py:494-527 —
+ * on the device for a likelihood the caller evaluates: no rsf_set_model, no observation, no forward solve in the library.
+ * They also pin that logic to the reference with no integrator in the loop: replaying the reference's recorded variates
+ * AND its recorded sums of squares must reproduce its chain to rounding.
+ *
+ *   rsf_mcmc_init_state   chains from an explicit state — q[C][d], ssq[C] (SSq at q), std2[C] (sigma^2, MCMC.py:261),
+ *                         V[C][d][d] (proposal covariance, MCMC.py:266) — instead of rsf_mcmc_init's own initial solves.
+ *                         cfg: n_params, n_chains, chain_offset, n0, prior_len, adapt_mode, adapt_interval, lo, hi are used.
+ *                         Such chains advance by rsf_mcmc_replay_ssq only (rsf_mcmc_run / rsf_mcmc_replay: RSF_ERR_STATE).
+ *   rsf_mcmc_propose      the proposal the NEXT iteration will make from z[C][d]: q_new[C][d] = q + chol(V) z, and
+ *                         in_bounds[C] (1 = strictly inside the box, i.e. the caller owes its sum of squares).  No state changes.
+ *   rsf_mcmc_replay_ssq   rsf_mcmc_replay with the proposals' sums of squares supplied: ssq_new[n_iters][C], read where
+ *                         the proposal is in bounds.  Works on chains made by either init call. */
+int rsf_mcmc_init_state(rsf_ctx *ctx, const rsf_mcmc_config *cfg, const double *q, const double *ssq, const double *std2,
+                        const double *V);
+int rsf_mcmc_propose(rsf_ctx *ctx, const double *z, double *q_new, uint8_t *in_bounds);
+int rsf_mcmc_replay_ssq(rsf_ctx *ctx, int64_t n_iters, const double *z, const double *u, const double *g,
+                        const double *ssq_new, double *trace_q, double *trace_std2, uint8_t *trace_accept);
+
 /* ---- posterior post-processing on pooled samples (RSF.plot_dist, RSF.py:717-746) -------------- */
 
 /* Moments of n samples x[i*stride] (stride in doubles selects one parameter of a [n][d] trace block):
@@ -266,7 +317,7 @@ int rsf_mcmc_draws(uint64_t seed, int64_t chain, int64_t iteration, int32_t n_pa
  * adapt_interval columns of qparams), computed on the device by the sampler's own adaptation arithmetic.  V_out[d][d] is
  * what the reference's loop would assign to Vold (MCMC.py:525): RSF_ADAPT_REFERENCE_DICT — the Cholesky FACTOR of
  * 2.38^2/prior_len * cov(window) (the quirk: it is then used as a covariance; d = 1 only; prior_len 0 => 2);
- * RSF_ADAPT_AM — 2.38^2/d * cov(window).  RSF_ERR_INVALID when that matrix is not positive definite (where
+ * RSF_ADAPT_AM — 2.38^2/d * cov(window).  RSF_ERR_NOT_POSDEF when that matrix is not positive definite (where
  * np.linalg.cholesky raises and the reference keeps its covariance, MCMC.py:524-527).  Host arrays; for callers that
  * compose the sampler's sub-steps themselves. */
 int rsf_mcmc_adapt(int32_t n_params, int32_t n, const double *window, int32_t adapt_mode, int32_t prior_len, double *V_out);

@@ -271,6 +271,31 @@ def rsf_driver_vectors(nsamples=30, seed_data=7, seed_chains=11):
                             "sequential per-Dc chains"), f, indent=1)
 
 
+def duck_model_vectors():
+    """Round 4: the reference's sampler on a model that is not a rate-and-state model (tests/duck_model.py: any object with
+    .Dc and .evaluate(), MCMC.py:65-66, 127) — list prior (never adapts), dict prior (the adaptation quirk) and a box tight
+    enough for out-of-bounds proposals.  Pins the drop-in's duck-typed path: same seed => same chain."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
+    from duck_model import observation
+
+    out, meta = {}, dict(source="MCMC(model=tests/duck_model.DecayModel).sample(False), MCMC.py:391-544", cases=[])
+    for tag, prior, qstart, nsamples in (("list", ["Uniform", 0.5, 40.0], 6.0, 150), ("dict", {1: 0.5, 2: 40.0}, 6.0, 150),
+                                         ("tightbox", ["Uniform", 3.93, 4.02], 3.98, 100)):
+        model, data = observation()
+        mc = MCMC(model, data, 4.0, prior, qstart, nsamples=nsamples, lstm_model=None, adapt_interval=10)
+        np.random.seed(99)
+        with quiet():
+            qp = mc.sample(False)
+        out[f"{tag}_data"], out[f"{tag}_qparams"], out[f"{tag}_std2"] = data, qp, np.asarray(mc.std2)
+        out[f"{tag}_vstart"] = np.asarray(mc.Vstart)
+        meta["cases"].append(dict(tag=tag, prior=prior if isinstance(prior, list) else {str(k): v for k, v in prior.items()},
+                                  prior_is_dict=not isinstance(prior, list), qstart=qstart, nsamples=nsamples, dc_true=4.0,
+                                  seed_data=314, seed_chain=99, model_calls=model.calls))
+    np.savez_compressed(os.path.join(OUT, "duck_model.npz"), **out)
+    with open(os.path.join(OUT, "duck_model.json"), "w") as f:
+        json.dump(meta, f, indent=1)
+
+
 def json_fixtures():
     """Files written by the REFERENCE's json_save_load.save_object (json_save_load.py:37-39, 128-130): an ndarray and a
     dict of ndarrays (nested, 2-D and scalar members) — fixtures for the repo's load_object / byte-equal save_object."""
@@ -290,8 +315,12 @@ if __name__ == "__main__":
     ap.add_argument("--only-nondefault", action="store_true", help="write only forward_nondefault.* (added later)")
     ap.add_argument("--only-round2", action="store_true", help="write only the vectors added in round 2 (rsf_driver.*, "
                     "ref_written_*.json, replay_dict3.*)")
+    ap.add_argument("--only-round4", action="store_true", help="write only the vectors added in round 4 (duck_model.*)")
     args = ap.parse_args()
     os.makedirs(OUT, exist_ok=True)
+    duck_model_vectors()
+    if args.only_round4:
+        sys.exit(0)
     rsf_driver_vectors()
     json_fixtures()
     replay_vectors("dict3", {0: "Uniform", 1: 0.0, 2: 10000.0}, 1000.0, 120)

@@ -127,8 +127,10 @@ struct rsf_ctx {
   double *q, *ssq, *std2, *V;   /* [C][d], [C], [C], [C][d][d] */
   double *wref, *wsum, *wsq;    /* adaptation window: shift [C][d], sums [C][d], [C][d][d] */
   int32_t *wn;                  /* [C] samples in window */
+  double *wbuf;                 /* reference_dict: the window itself, [C][adapt_interval] (np.cov's own arithmetic needs the samples) */
   int64_t iters_done;
-  int64_t n_acc, n_eval, n_nonfinite;
+  int64_t n_acc, n_eval, n_nonfinite, n_oob;
+  int external_chains;          /* made by rsf_mcmc_init_state: no observation, advanced by rsf_mcmc_replay_ssq only */
   int32_t world, rank;          /* world 0: rsf_comm_init not called */
   void *comm;                   /* world > 1: communicator of the nccl implementation named by RSF_RCCL_LIB (tests/c/fake_rccl.c) */
 };
@@ -154,9 +156,10 @@ int rsf_create(const rsf_config *cfg, rsf_ctx **out) {
 
 static void free_chains(rsf_ctx *c) {
   free(c->data); free(c->q); free(c->ssq); free(c->std2); free(c->V);
-  free(c->wref); free(c->wsum); free(c->wsq); free(c->wn);
+  free(c->wref); free(c->wsum); free(c->wsq); free(c->wn); free(c->wbuf);
   c->data = c->q = c->ssq = c->std2 = c->V = c->wref = c->wsum = c->wsq = NULL;
   c->wn = NULL;
+  c->wbuf = NULL;
   c->have_chains = 0;
 }
 
@@ -546,6 +549,11 @@ int rsf_mcmc_init(rsf_ctx *c, const rsf_mcmc_config *cfg, const double *q0, cons
   c->wsum = (double *)calloc(C * d, sizeof(double));
   c->wsq = (double *)calloc(C * d * d, sizeof(double));
   c->wn = (int32_t *)calloc(C, sizeof(int32_t));
+  if (cfg->adapt_mode == RSF_ADAPT_REFERENCE_DICT) {
+    if (cfg->adapt_interval > RSF_DICT_MAX_INTERVAL) { free_chains(c); return fail(RSF_ERR_UNSUPPORTED, "reference_dict adaptation keeps at most RSF_DICT_MAX_INTERVAL (128) samples per window"); }
+    c->wbuf = (double *)calloc((size_t)C * cfg->adapt_interval, sizeof(double));
+    if (!c->wbuf) { free_chains(c); return fail(RSF_ERR_NOMEM, "rsf_mcmc_init: out of memory"); }
+  }
   if (!c->data || !c->q || !c->ssq || !c->std2 || !c->V || !c->wref || !c->wsum || !c->wsq || !c->wn) {
     free_chains(c);
     return fail(RSF_ERR_NOMEM, "rsf_mcmc_init: out of memory");
@@ -598,8 +606,9 @@ int rsf_mcmc_init(rsf_ctx *c, const rsf_mcmc_config *cfg, const double *q0, cons
     free(accp);
   }
   c->iters_done = 0;
-  c->n_acc = c->n_eval = c->n_nonfinite = 0;
+  c->n_acc = c->n_eval = c->n_nonfinite = c->n_oob = 0;
   c->have_chains = 1;
+  c->external_chains = 0;
   return RSF_OK;
 }
 
@@ -627,10 +636,48 @@ int rsf_mcmc_set_state(rsf_ctx *c, const double *q, const double *ssq, const dou
   return RSF_OK;
 }
 
+/* np.add.reduce over n contiguous doubles as NumPy performs it (numpy/_core/src/umath/loops_utils.h.src, *_pairwise_sum):
+ * fewer than 8 elements are added one by one from 0; up to 128 go through eight interleaved accumulators that are then
+ * combined pairwise, the remainder added one by one; longer runs are halved (the first half a multiple of 8) recursively.
+ * The ORDER is the point: whether the mean of a window of identical samples comes out as that sample — np.cov exactly 0,
+ * np.linalg.cholesky raises, the reference keeps its covariance (MCMC.py:524-527) — or one ulp off — np.cov ~1e-31,
+ * the Cholesky "succeeds" and the reference's proposal collapses to ~1e-8 until the next windows widen it again — depends on it. */
+static double np_pairwise_sum(const double *a, int64_t n) {
+  if (n < 8) {
+    double res = 0.0;
+    for (int64_t i = 0; i < n; ++i) res += a[i];
+    return res;
+  }
+  if (n <= 128) {
+    double r[8];
+    int64_t i;
+    for (int j = 0; j < 8; ++j) r[j] = a[j];
+    for (i = 8; i < n - (n % 8); i += 8)
+      for (int j = 0; j < 8; ++j) r[j] += a[i + j];
+    double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    for (; i < n; ++i) res += a[i];
+    return res;
+  }
+  int64_t n2 = n / 2;
+  n2 -= n2 % 8;
+  return np_pairwise_sum(a, n2) + np_pairwise_sum(a + n2, n - n2);
+}
+
+/* np.cov(x) of ONE variable with n observations, as numpy/lib/_function_base_impl.py::cov forms it: avg = sum / n (the sum
+ * above), X -= avg, c = dot(X, X^T), c *= 1 / (n - 1).  (The dot product's own summation order is BLAS's and moves c by an
+ * ulp at most; the mean's order decides zero against non-zero.)  This is the arithmetic behind MCMC.py:200-203 for the
+ * reference's one-parameter chains; `reference_dict` adaptation uses it so that degenerate windows behave as they do there. */
+static double np_cov_1d(const double *x, int32_t n) {
+  const double avg = np_pairwise_sum(x, n) / (double)n;
+  double c = 0.0;
+  for (int32_t k = 0; k < n; ++k) { double dlt = x[k] - avg; c += dlt * dlt; }
+  return c * (1.0 / (double)(n - 1));
+}
+
 /* One chain, n_iters iterations of MCMC.py:494-527. */
 static void run_chain(rsf_ctx *c, int64_t i, int64_t n_iters, const double *zs, const double *us,
-                      const double *gs, double *tq, double *ts, uint8_t *ta, int64_t *acc_cnt,
-                      int64_t *eval_cnt, int64_t *nonfinite_cnt) {
+                      const double *gs, const double *sn, double *tq, double *ts, uint8_t *ta, int64_t *acc_cnt,
+                      int64_t *eval_cnt, int64_t *nonfinite_cnt, int64_t *oob_cnt) {
   const rsf_mcmc_config *mc = &c->mc;
   const int d = mc->n_params;
   const int64_t C = mc->n_chains;
@@ -661,8 +708,9 @@ static void run_chain(rsf_ctx *c, int64_t i, int64_t n_iters, const double *zs, 
     /* acceptreject, MCMC.py:318-333 */
     int inb = 1, accept = 0;
     for (int p = 0; p < d; ++p) inb = inb && (qn[p] > mc->lo[p]) && (qn[p] < mc->hi[p]);
+    if (!inb) ++*oob_cnt;
     if (inb) {
-      double ssqn = ssq_of(c, i, qn, d);
+      double ssqn = sn ? sn[n * C + i] : ssq_of(c, i, qn, d);   /* rsf_mcmc_replay_ssq: the caller evaluated the model */
       double u;
       if (us) u = us[n * C + i];
       else { uint32_t w[4]; draw_words(mc->seed, gid, it, SLOT_U, w); u = u53(w[0], w[1]); }
@@ -690,6 +738,7 @@ static void run_chain(rsf_ctx *c, int64_t i, int64_t n_iters, const double *zs, 
         for (int r = 0; r < d; ++r) wq[p * d + r] += (q[p] - wr[p]) * (q[r] - wr[r]);
       }
       c->wn[i] += 1;
+      if (c->wbuf) c->wbuf[i * mc->adapt_interval + (c->iters_done + n) % mc->adapt_interval] = q[0];
       if ((c->iters_done + n + 1) % mc->adapt_interval == 0) {
         const double nn = (double)c->wn[i];
         double cov[9], Vn[9], Ln[9];
@@ -698,8 +747,10 @@ static void run_chain(rsf_ctx *c, int64_t i, int64_t n_iters, const double *zs, 
             for (int r = 0; r < d; ++r)
               cov[p * d + r] = (wq[p * d + r] - ws[p] * ws[r] / nn) / (nn - 1.0); /* np.cov, ddof=1 */
           if (mc->adapt_mode == RSF_ADAPT_REFERENCE_DICT) {
-            /* d := len(qpriors.keys()) (MCMC.py:200; 2 for {1: lo, 2: hi}); the Cholesky FACTOR becomes the next covariance */
-            Vn[0] = 2.38 * 2.38 / (double)(mc->prior_len > 0 ? mc->prior_len : 2) * cov[0];
+            /* d := len(qpriors.keys()) (MCMC.py:200; 2 for {1: lo, 2: hi}); the Cholesky FACTOR becomes the next covariance.
+             * The window is the last adapt_interval samples in order (the ring is full and starts at slot 0 whenever an
+             * adaptation is due), its covariance np.cov's own arithmetic. */
+            Vn[0] = 2.38 * 2.38 / (double)(mc->prior_len > 0 ? mc->prior_len : 2) * np_cov_1d(c->wbuf + i * mc->adapt_interval, mc->adapt_interval);
             if (chol_lower(Vn, 1, Ln)) V[0] = Ln[0];
           } else {
             for (int e = 0; e < d * d; ++e) Vn[e] = 2.38 * 2.38 / (double)d * cov[e];
@@ -718,28 +769,101 @@ static void run_chain(rsf_ctx *c, int64_t i, int64_t n_iters, const double *zs, 
   memcpy(c->V + i * d * d, V, sizeof(double) * d * d);
 }
 
-static int run_all(rsf_ctx *c, int64_t n_iters, const double *z, const double *u, const double *g,
+static int run_all(rsf_ctx *c, int64_t n_iters, const double *z, const double *u, const double *g, const double *sn,
                    double *tq, double *ts, uint8_t *ta) {
   if (!c || n_iters < 0) return fail(RSF_ERR_INVALID, "rsf_mcmc_run: bad argument");
   if (!c->have_chains) return fail(RSF_ERR_STATE, "rsf_mcmc_run: call rsf_mcmc_init first");
-  int64_t a = 0, e = 0, nf = 0;
+  if (c->external_chains && !sn)
+    return fail(RSF_ERR_STATE, "chains made by rsf_mcmc_init_state have no observation: advance them with rsf_mcmc_replay_ssq");
+  int64_t a = 0, e = 0, nf = 0, ob = 0;
   int nt = nthreads(c);
   (void)nt;
-#pragma omp parallel for schedule(static) reduction(+ : a, e, nf) num_threads(nt)
-  for (int64_t i = 0; i < c->mc.n_chains; ++i) run_chain(c, i, n_iters, z, u, g, tq, ts, ta, &a, &e, &nf);
-  c->n_acc += a; c->n_eval += e; c->n_nonfinite += nf;
+#pragma omp parallel for schedule(static) reduction(+ : a, e, nf, ob) num_threads(nt)
+  for (int64_t i = 0; i < c->mc.n_chains; ++i) run_chain(c, i, n_iters, z, u, g, sn, tq, ts, ta, &a, &e, &nf, &ob);
+  c->n_acc += a; c->n_eval += e; c->n_nonfinite += nf; c->n_oob += ob;
   c->iters_done += n_iters;
   return RSF_OK;
 }
 
 int rsf_mcmc_run(rsf_ctx *c, int64_t n_iters, double *tq, double *ts, uint8_t *ta) {
-  return run_all(c, n_iters, NULL, NULL, NULL, tq, ts, ta);
+  return run_all(c, n_iters, NULL, NULL, NULL, NULL, tq, ts, ta);
 }
 
 int rsf_mcmc_replay(rsf_ctx *c, int64_t n_iters, const double *z, const double *u, const double *g,
                     double *tq, double *ts, uint8_t *ta) {
   if (!z || !u || !g) return fail(RSF_ERR_INVALID, "rsf_mcmc_replay: z, u and g are required");
-  return run_all(c, n_iters, z, u, g, tq, ts, ta);
+  return run_all(c, n_iters, z, u, g, NULL, tq, ts, ta);
+}
+
+int rsf_mcmc_replay_ssq(rsf_ctx *c, int64_t n_iters, const double *z, const double *u, const double *g, const double *ssq_new,
+                        double *tq, double *ts, uint8_t *ta) {
+  if (!z || !u || !g || !ssq_new) return fail(RSF_ERR_INVALID, "rsf_mcmc_replay_ssq: z, u, g and ssq_new are required");
+  return run_all(c, n_iters, z, u, g, ssq_new, tq, ts, ta);
+}
+
+/* chains from an explicit state: MCMC.py:464-468 done by the caller (any model object), MCMC.py:494-527 here */
+int rsf_mcmc_init_state(rsf_ctx *c, const rsf_mcmc_config *cfg, const double *q, const double *ssq, const double *std2, const double *V) {
+  if (!c || !cfg || !q || !ssq || !std2 || !V) return fail(RSF_ERR_INVALID, "rsf_mcmc_init_state: NULL argument");
+  if (cfg->size != sizeof(rsf_mcmc_config)) return fail(RSF_ERR_INVALID, "rsf_mcmc_init_state: struct size mismatch");
+  if (cfg->n_params != 1 && cfg->n_params != 3) return fail(RSF_ERR_UNSUPPORTED, "rsf_mcmc_init_state: n_params must be 1 or 3");
+  if (cfg->n_chains < 1) return fail(RSF_ERR_INVALID, "rsf_mcmc_init_state: n_chains < 1");
+  if (cfg->adapt_mode == RSF_ADAPT_REFERENCE_DICT && cfg->n_params != 1)
+    return fail(RSF_ERR_UNSUPPORTED, "rsf_mcmc_init_state: reference_dict adaptation is defined for 1 parameter only");
+  if (cfg->adapt_mode < 0 || cfg->adapt_mode > RSF_ADAPT_AM || (cfg->adapt_mode && cfg->adapt_interval < 2))
+    return fail(RSF_ERR_INVALID, "rsf_mcmc_init_state: bad adapt_mode / adapt_interval");
+  free_chains(c);
+  c->mc = *cfg;
+  c->n_groups = 1;
+  const int d = cfg->n_params;
+  const int64_t C = cfg->n_chains;
+  c->q = (double *)malloc(sizeof(double) * C * d);
+  c->ssq = (double *)malloc(sizeof(double) * C);
+  c->std2 = (double *)malloc(sizeof(double) * C);
+  c->V = (double *)malloc(sizeof(double) * C * d * d);
+  c->wref = (double *)malloc(sizeof(double) * C * d);
+  c->wsum = (double *)calloc(C * d, sizeof(double));
+  c->wsq = (double *)calloc(C * d * d, sizeof(double));
+  c->wn = (int32_t *)calloc(C, sizeof(int32_t));
+  if (cfg->adapt_mode == RSF_ADAPT_REFERENCE_DICT) {
+    if (cfg->adapt_interval > RSF_DICT_MAX_INTERVAL) { free_chains(c); return fail(RSF_ERR_UNSUPPORTED, "reference_dict adaptation keeps at most RSF_DICT_MAX_INTERVAL (128) samples per window"); }
+    c->wbuf = (double *)calloc((size_t)C * cfg->adapt_interval, sizeof(double));
+    if (!c->wbuf) { free_chains(c); return fail(RSF_ERR_NOMEM, "rsf_mcmc_init_state: out of memory"); }
+  }
+  if (!c->q || !c->ssq || !c->std2 || !c->V || !c->wref || !c->wsum || !c->wsq || !c->wn) {
+    free_chains(c);
+    return fail(RSF_ERR_NOMEM, "rsf_mcmc_init_state: out of memory");
+  }
+  memcpy(c->q, q, sizeof(double) * C * d);
+  memcpy(c->wref, q, sizeof(double) * C * d);
+  memcpy(c->ssq, ssq, sizeof(double) * C);
+  memcpy(c->std2, std2, sizeof(double) * C);
+  memcpy(c->V, V, sizeof(double) * C * d * d);
+  c->iters_done = 0;
+  c->n_acc = c->n_eval = c->n_nonfinite = c->n_oob = 0;
+  c->have_chains = 1;
+  c->external_chains = 1;
+  return RSF_OK;
+}
+
+/* the proposal the next iteration makes from z (MCMC.py:497) and its box test (MCMC.py:318-320); nothing changes */
+int rsf_mcmc_propose(rsf_ctx *c, const double *z, double *q_new, uint8_t *in_bounds) {
+  if (!c || !z || !q_new || !in_bounds) return fail(RSF_ERR_INVALID, "rsf_mcmc_propose: NULL argument");
+  if (!c->have_chains) return fail(RSF_ERR_STATE, "rsf_mcmc_propose: call rsf_mcmc_init or rsf_mcmc_init_state first");
+  const rsf_mcmc_config *mc = &c->mc;
+  const int d = mc->n_params;
+  for (int64_t i = 0; i < mc->n_chains; ++i) {
+    double L[9];
+    int inb = 1;
+    chol_lower(c->V + i * d * d, d, L);
+    for (int p = 0; p < d; ++p) {
+      double s = c->q[i * d + p];
+      for (int r = 0; r <= p; ++r) s += L[p * d + r] * z[i * d + r];
+      q_new[i * d + p] = s;
+      inb = inb && (s > mc->lo[p]) && (s < mc->hi[p]);
+    }
+    in_bounds[i] = (uint8_t)inb;
+  }
+  return RSF_OK;
 }
 
 int rsf_mcmc_stats(rsf_ctx *c, int64_t *n_acc, int64_t *n_eval, int64_t *n_nonfinite, int64_t *n_done) {
@@ -749,6 +873,17 @@ int rsf_mcmc_stats(rsf_ctx *c, int64_t *n_acc, int64_t *n_eval, int64_t *n_nonfi
   if (n_eval) *n_eval = c->n_eval;
   if (n_nonfinite) *n_nonfinite = c->n_nonfinite;
   if (n_done) *n_done = c->iters_done;
+  return RSF_OK;
+}
+
+/* the counters that are properties of the chains; the wave-level ones describe the HIP kernels and are zero here */
+int rsf_mcmc_counters(rsf_ctx *c, int64_t *out, int32_t n) {
+  if (!c || !out || n < 0) return fail(RSF_ERR_INVALID, "rsf_mcmc_counters: bad argument");
+  if (!c->have_chains) return fail(RSF_ERR_STATE, "rsf_mcmc_counters: call rsf_mcmc_init first");
+  int64_t v[RSF_CNT_COUNT] = {0};
+  v[RSF_CNT_ACCEPTED] = c->n_acc; v[RSF_CNT_EVALUATED] = c->n_eval; v[RSF_CNT_NONFINITE] = c->n_nonfinite;
+  v[RSF_CNT_OUT_OF_BOUNDS] = c->n_oob;
+  for (int32_t k = 0; k < n && k < RSF_CNT_COUNT; ++k) out[k] = v[k];
   return RSF_OK;
 }
 
@@ -997,8 +1132,12 @@ int rsf_mcmc_adapt(int32_t d, int32_t n, const double *window, int32_t adapt_mod
       cov[p * d + r] = n > 1 ? s / (double)(n - 1) : 0.0;  /* np.cov, ddof = 1 */
     }
   const double scale = adapt_mode == RSF_ADAPT_REFERENCE_DICT ? 2.38 * 2.38 / (double)(prior_len > 0 ? prior_len : 2) : 2.38 * 2.38 / (double)d;
+  if (adapt_mode == RSF_ADAPT_REFERENCE_DICT) {
+    if (n > RSF_DICT_MAX_INTERVAL) return fail(RSF_ERR_UNSUPPORTED, "rsf_mcmc_adapt: reference_dict windows hold at most RSF_DICT_MAX_INTERVAL (128) samples");
+    if (n > 1) cov[0] = np_cov_1d(window, n);  /* np.cov's own arithmetic, like the sampler's (run_chain) */
+  }
   for (int e = 0; e < d * d; ++e) Vn[e] = scale * cov[e];
-  if (n < 2 || !chol_lower(Vn, d, Ln)) return fail(RSF_ERR_INVALID, "rsf_mcmc_adapt: the window's covariance is not positive definite");
+  if (n < 2 || !chol_lower(Vn, d, Ln)) return fail(RSF_ERR_NOT_POSDEF, "rsf_mcmc_adapt: the window's covariance is not positive definite");
   memcpy(V_out, adapt_mode == RSF_ADAPT_REFERENCE_DICT ? Ln : Vn, sizeof(double) * d * d);
   return RSF_OK;
 }

@@ -253,11 +253,19 @@ def test_inference_slices_and_chains_equal_the_reference(pkg, golden, oracle_lib
 
     problem2 = _rsf_problem(pkg, meta)
     problem2.data, problem2.format = g["data"], "json"
-    monkeypatch.setattr(pkg.MCMC, "_vstart_override", staticmethod(checker_vstart))
+    device_init = pkg.MCMC.compute_initial_covariance
+
+    def init_with_checker_vstart(mc):  # the product's own init, then the proposal covariance replaced by the checker's
+        device_init(mc)
+        v = checker_vstart(mc)
+        mc._engine().set_state(V=np.reshape(v, (1, 1, 1)))
+        mc.Vstart = np.array([[v]])
+
+    monkeypatch.setattr(pkg.MCMC, "compute_initial_covariance", init_with_checker_vstart)
     np.random.seed(meta["seed_chains"])
     with redirect_stdout(io.StringIO()):
         problem2.inference(meta["nsamples"])
-    monkeypatch.setattr(pkg.MCMC, "_vstart_override", None)
+    monkeypatch.setattr(pkg.MCMC, "compute_initial_covariance", device_init)
     for i, dc in enumerate(g["dc_list"]):
         np.testing.assert_allclose(problem2.posteriors[float(dc)], g[f"qparams_{i}"], rtol=1e-9, err_msg=f"dc {dc} (checker Vstart)")
     N = meta["number_time_steps"]

@@ -88,14 +88,42 @@ def test_mcmc_public_submethods(pkg, model, golden):
     with pytest.raises(NotImplementedError):
         pkg.MCMC(model, g["data"], 1000.0, ["Uniform", 0.0, 1e4], 1000.0, lstm_model={"x": 1}).sample(False)
 
-    class Duck:
-        Dc = None
+    with pytest.raises(NotImplementedError):  # the quirk mode is the reference's: one parameter (MCMC.py:98, 381)
+        mcd.update_covariance_matrix(np.arange(40.0).reshape(2, -1))
+    with pytest.raises(np.linalg.LinAlgError):  # a window that never moved: np.linalg.cholesky's failure, and only that one
+        mcd.update_covariance_matrix(np.full((1, 20), 3.0))
 
-        def evaluate(self):
-            return None, np.zeros(500), None
 
+def test_any_model_with_dc_and_evaluate_is_accepted(pkg, oracle_lib):
+    """The reference's model contract (MCMC.py:65-66, 127, 381-384): a settable .Dc and .evaluate()[1].  Such a model is
+    evaluated on the host, its chain steps run on the engine (here the checker, injected); the batched device path, which
+    integrates the model itself, says what it needs instead.  Without a GPU the product's own engine fails loudly."""
+    from duck_model import observation
+
+    model, data = observation()
+    mc = pkg.MCMC(model, data, 4.0, ["Uniform", 0.5, 40.0], 6.0, nsamples=12, lstm_model=None, verbose=False)
+    if pkg._abi.load().rsf_device_count() <= 0:
+        with pytest.raises(pkg._abi.RsfError):
+            mc.sample(False)
+    mc._host_engine = pkg.Engine(lib=oracle_lib)
+    calls = model.calls
+    s = mc.SSqcalc(np.array([[4.0]]))
+    assert s.shape == (1, 1) and model.calls == calls + 1 and np.asarray(model.Dc).shape == (1,)  # a 1-element array, MCMC.py:381
+    np.random.seed(5)
+    out = mc.sample(False)
+    assert out.shape == (1, 12 + 1 - 6) and mc.std2.shape == (7,) and 0.0 <= mc.acceptance_ratio <= 1.0
+    # the sub-methods work on such a model too (host evaluation, device chain step)
+    acc, s_new = mc.acceptreject(np.array([[100.0]]), s, 1e-3)  # out of bounds: the model is not called
+    assert not acc and s_new is s
+    calls = model.calls
+    acc, s_new = mc.acceptreject(np.array([[4.0]]), s * 3, 1e-3)  # much better fit: accepted, one model call
+    assert acc and model.calls == calls + 1 and s_new[0, 0] == pytest.approx(s[0, 0])
+    mc.std2 = [1e-3]
+    mc.update_standard_deviation(s)
+    assert len(mc.std2) == 2 and mc.std2[-1] > 0
     with pytest.raises(TypeError):
-        pkg.MCMC(Duck(), g["data"], 1000.0, ["Uniform", 0.0, 1e4], 1000.0, lstm_model=None).sample(False)
+        mc.sample_batched(64)
+    mc._host_engine.close()
 
 
 def compose_like_the_reference_loop(mc, nsamples):

@@ -191,6 +191,43 @@ def test_sampler_logic_replays_reference_exactly(oracle_mod, golden, tag):
 
 
 @pytest.mark.parametrize("tag", ["list", "dict", "dict3", "tightbox"])
+def test_likelihood_operator_replays_reference_exactly(cpu_engine, golden, tag):
+    """The same through the C ABI's likelihood-operator calls on the checker library (rsf_mcmc_init_state, rsf_mcmc_propose,
+    rsf_mcmc_replay_ssq): one call for the whole run, then one call per iteration.  tests/test_gpu_parity.py runs the very
+    same checks on the HIP kernels."""
+    import likelihood_operator as lo
+
+    g, meta = golden.npz("replay_" + tag), golden.json("replay_" + tag)
+    lo.replay_in_one_call(cpu_engine, g, meta)
+    lo.replay_step_by_step(cpu_engine, g, meta)
+    # chains made from an explicit state have no observation: the solving entry points refuse them
+    import bayesian_markov_chain_monte_carlo_amd as pkg
+
+    with pytest.raises(pkg._abi.RsfError):
+        cpu_engine.mcmc_run(1)
+
+
+def test_dict_prior_adaptation_is_numpys_covariance_to_the_bit_that_matters(pkg, cpu_engine):
+    import likelihood_operator as lo
+
+    lo.adapt_matches_numpy_on_degenerate_windows(pkg, cpu_engine)
+
+
+def test_duck_typed_model_reproduces_the_reference_chain(pkg, cpu_engine, golden):
+    """MCMC(model=<any object with .Dc and .evaluate()>) — the reference's model contract (MCMC.py:65-66, 127, 381-384) — on
+    the checker library: the chain the REFERENCE's sampler produced on tests/duck_model.DecayModel under the same seed."""
+    import likelihood_operator as lo
+
+    for case in golden.json("duck_model")["cases"]:
+        qp, std2, vstart, calls, g = lo.duck_model_chain(pkg, golden, case, engine=cpu_engine)
+        tag = case["tag"]
+        assert qp.shape == g[f"{tag}_qparams"].shape and calls == case["model_calls"]
+        np.testing.assert_allclose(vstart, g[f"{tag}_vstart"], rtol=1e-12)
+        np.testing.assert_allclose(qp, g[f"{tag}_qparams"], rtol=1e-13)
+        np.testing.assert_allclose(std2, g[f"{tag}_std2"], rtol=1e-12)
+
+
+@pytest.mark.parametrize("tag", ["list", "dict", "dict3", "tightbox"])
 def test_c_oracle_replays_reference_chain(cpu_engine, oracle_mod, golden, tag):
     """C restatement with its own RK4 (S = 8) forward model, driven by the reference's variates."""
     g, meta = golden.npz("replay_" + tag), golden.json("replay_" + tag)
