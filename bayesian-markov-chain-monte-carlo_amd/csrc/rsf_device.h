@@ -346,11 +346,16 @@ __device__ __forceinline__ State initial_state(double dc, const Lane &L, const C
 
 // ---------------------------------------------------------------------------------------------
 // LDS staging.  Chunk c covers output samples k0 .. k0+kn-1 (k0 = 1 + c*kc): it needs
-// 2*S*kn+1 loading values and kn observations.  Layout: [ vl : 2*S*kc+1 ][ data : kc ].
+// 2*S*kn+1 loading values and kn observations.  Layout: [ vl : 2*S*kc+1 ][ data : kc ][ data_0 ] — the last word holds the
+// observation's sample 0, which belongs to no chunk (acc[0] = 0, RateStateModel.py:371: its square starts every sum of
+// squares).  Until round 4 every forward solve read it from global memory and waited for it: a cache round trip per
+// proposal, and — vector loads and stores retire in order on one counter — a wait for the trace row the previous iteration
+// had just stored.  With it staged here the sampler's iteration loop holds no vector load at all.
 // Every thread of the workgroup must call stage_chunk (it contains the barriers).
 // ---------------------------------------------------------------------------------------------
 constexpr int kLdsPad = 0;
 __device__ __forceinline__ int lds_data_offset(const Consts &K) { return 2 * K.S * K.kc + 1 + kLdsPad; }
+__device__ __forceinline__ int lds_d0_offset(const Consts &K) { return lds_data_offset(K) + K.kc; }
 
 __device__ __forceinline__ void stage_chunk(double *lds, const Consts &K, int k0, int kn) {
   const int nv = 2 * K.S * kn + 1;
@@ -360,6 +365,7 @@ __device__ __forceinline__ void stage_chunk(double *lds, const Consts &K, int k0
   if (K.data) {
     double *ld = lds + lds_data_offset(K);
     for (int i = threadIdx.x; i < kn; i += blockDim.x) ld[i] = K.data[k0 + i];
+    if (threadIdx.x == 0) lds[lds_d0_offset(K)] = K.data[0];
   }
   __syncthreads();
 }
@@ -643,14 +649,14 @@ __device__ __forceinline__ double solve(double *lds, const Consts &K, bool resid
   State s = initial_state(dc, L, K);
   wave_begin(W, active, L, K);
   double ssq = 0.0;
-  if (WANT_SSQ && active) {
-    const double d0 = K.data[0];  // sample 0 belongs to no chunk: acc[0] = 0, RateStateModel.py:371
-    ssq = d0 * d0;
-  }
   if (WANT_ACC && active) acc_out[0] = 0.0;
   for (int k0 = 1; k0 < K.nout; k0 += K.kc) {
     const int kn = min(K.kc, K.nout - k0);
     if (!resident) stage_chunk(lds, K, k0, kn);
+    if (WANT_SSQ && k0 == 1) {  // sample 0 belongs to no chunk: acc[0] = 0, RateStateModel.py:371 (staged with every chunk)
+      const double d0 = lds[lds_d0_offset(K)];
+      ssq = d0 * d0;
+    }
     // a wave-uniform branch: every lane of a wave with work goes in — the lanes that are not `active` (out of bounds, past
     // the end of the batch) ride along masked out of W.alive and of the trajectory stores.  (Under `if (active)`, a divergent
     // branch, everything the solve leaves in W would count as divergent after it and move from scalar to vector registers.)

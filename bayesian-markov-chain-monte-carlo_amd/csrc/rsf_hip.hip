@@ -625,8 +625,8 @@ int rsf_set_model(rsf_ctx *c, const rsf_model *m) {
       x = x + hk;
     }
   } else {
-    // LDS chunking: kc output intervals need (2*S*kc + 1) loading values + kc observations
-    kc = ((int64_t)words - 1) / (2 * (int64_t)S + 1);
+    // LDS chunking: kc output intervals need (2*S*kc + 1) loading values + kc observations + the observation's sample 0
+    kc = ((int64_t)words - 2) / (2 * (int64_t)S + 1);
     if (kc < 1) return fail(RSF_ERR_UNSUPPORTED, "rsf_set_model: substeps=%d does not fit the LDS staging budget", S);
     if (kc > nout - 1) kc = nout - 1;
     // chain-independent loading velocity at every RK4 stage time, RateStateModel.py:327-329
@@ -646,7 +646,7 @@ int rsf_set_model(rsf_ctx *c, const rsf_model *m) {
   c->delta_t = delta_t; c->h = h; c->nout = nout;
   c->kc = (int32_t)kc;
   c->nchunks = (int32_t)((nout - 1 + kc - 1) / kc);
-  c->lds_bytes = (size_t)((dop ? rsf::dp::kTab * kc : 2 * S * kc + 1) + kc + 2 * rsf::kLdsPad) * sizeof(double);
+  c->lds_bytes = (size_t)((dop ? rsf::dp::kTab * kc : 2 * S * kc + 1) + kc + 1 + 2 * rsf::kLdsPad) * sizeof(double);
   c->have_model = true;
   return RSF_OK;
 }

@@ -352,17 +352,22 @@ __device__ __forceinline__ void propose(const double (&q)[D], F factor, const do
   }
 }
 
-template <int D>
-__device__ __forceinline__ bool in_box(const double (&qn)[D], const double *lo, const double *hi) {
+// (ARGS: a kernel-argument struct with lo[] / hi[] members, indexed in place — a pointer INTO the argument block would make
+// these per-lane flat loads, on the vector-memory counter the trace stores sit on, instead of scalar loads)
+template <int D, typename ARGS>
+__device__ __forceinline__ bool in_box(const double (&qn)[D], const ARGS &A) {
   bool inb = true;
 #pragma unroll
-  for (int p = 0; p < D; ++p) inb = inb && (qn[p] > lo[p]) && (qn[p] < hi[p]);  // strict box, MCMC.py:318-320
+  for (int p = 0; p < D; ++p) inb = inb && (qn[p] > A.lo[p]) && (qn[p] < A.hi[p]);  // strict box, MCMC.py:318-320
   return inb;
 }
 
 // Per-wave statistics of a sampler launch: wave-uniform 32-bit accumulators (scalar registers), added to the ctx totals
 // (McmcArgs::stats, 64-bit) by the wave's first lane.  Index = RSF_CNT_* of rsf_abi.h.
-constexpr int kFlushEvery = 16;  // proposals between flushes: 16 x 4000 x 8 sub-steps x 64 lanes < 2^32
+constexpr int kFlushEvery = 16;  // rounds between flushes: 16 x 4000 x 8 sub-steps x 64 lanes < 2^32
+// tries a lane gets per forward solve to come up with a proposal inside the prior box (mcmc_kernel): with four, at the 39 %
+// out-of-bounds rate of the reference's main.py problem 2 % of the lanes still enter a solve idle, for three short rounds
+constexpr int kProposalTries = 4;
 struct WaveCounters {
   uint32_t accepted, evaluated, nonfinite, oob, early, wave_solves, wave_skips;
   rsf::Wave W;  // the running solve's control, and steps per tier / redone / lane_steps accumulated over the solves
@@ -418,7 +423,6 @@ __global__ void __launch_bounds__(kMaxBlock, kMinBlocks) mcmc_kernel(Consts K, M
   const int64_t i = blk + t;
   const bool valid = i < A.C;
   auto at = [&](auto *base, int e) { return base + ((int64_t)e * A.C + blk); };  // wave-uniform
-  const uint64_t gid = (uint64_t)(A.chain_offset + i);  // RNG is keyed by the GLOBAL chain id
   const bool resident = K.nchunks == 1;
 
   double q[D];
@@ -426,11 +430,14 @@ __global__ void __launch_bounds__(kMaxBlock, kMinBlocks) mcmc_kernel(Consts K, M
 #pragma unroll
   for (int p = 0; p < D; ++p) q[p] = 1.0;
   // What a proposal needs of the covariance V is its lower Cholesky factor (MCMC.py:497).  D = 1: one double, sqrt(V), kept
-  // in a register with the three doubles of the adaptation window.  D = 3: the factor's six doubles live in LDS, one slot
-  // per lane behind the table chunk (lc[e][lane]: conflict-free), formed from V once per launch and again when the chain
-  // adapts; the window (3 + 3 + 9 doubles of shifted sums) stays in its HBM arrays and is read-modified-written once per
-  // proposal when the chain adapts at all — registers across the forward solve belong to the integrator.
-  constexpr bool kWinRegs = D == 1;
+  // in a register.  D = 3: the factor's six doubles live in LDS, one slot per lane behind the table chunk (lc[e][lane]:
+  // conflict-free), formed from V once per launch and again when the chain adapts.  The adaptation window (D + D + D^2
+  // doubles of shifted sums) stays in its HBM arrays and is read-modified-written once per proposal when the chain adapts at
+  // all — registers across the forward solve belong to the integrator.  (Until round 4 the one-parameter window sat in
+  // registers for the launch: seven of them held across every solve, also when nothing adapts — the BASELINE case — and
+  // with them the kernel spilled loop-invariant values whose reload, at the top of every solve, waited for the trace row
+  // just stored: vector stores and scratch loads share one counter.)
+  constexpr bool kWinRegs = false;
   double *lcs = lds + A.lc_off + t;  // D = 3: element e of this lane's factor at lcs[e * blockDim.x]
   double V1 = 0.0;                             // D = 1: the proposal variance
   double wr[D], ws[D], wq[D * D];
@@ -482,104 +489,145 @@ __global__ void __launch_bounds__(kMaxBlock, kMinBlocks) mcmc_kernel(Consts K, M
     else rsf::stage_chunk(lds, K, 1, K.nout - 1);
   }
 
-  for (int64_t n = 0; n < A.n_iters; ++n) {
-    const uint32_t it = (uint32_t)(A.iter_base + n);
-    const int64_t row0 = n * A.C + blk;  // trace row of this workgroup's first chain (wave-uniform)
-    // the lane's offset as this iteration sees it: opaque, so that the addresses built from it are formed where they are
+  // The chain's current point, sigma^2, SSq and the logarithm of the accept test's uniform wait out the forward solve in LDS
+  // (per-lane slots behind the table chunk; D = 3: behind the Cholesky factor's six) instead of in registers the
+  // integrator needs — the spills per proposal these kernels had otherwise.
+  constexpr bool kPark = MODE == RK4_F64;  // (the DOP853 kernel allocates worse with it: measured, tools/one_kernel.sh)
+  constexpr int kSlotQ = D == 3 ? 6 : 0, kSlotStd2 = kSlotQ + D, kSlotSsq = kSlotStd2 + 1, kSlotLu = kSlotSsq + 1;
+  static_assert(kSlotLu + 1 == kParkSlots<D>, "rsf_hip.hip sizes the launch's LDS with kParkSlots");
+
+  // Every lane walks its OWN chain through iterations 0 .. n_iters-1 (nl: the lane's next one).  A round of the loop below
+  // gives every lane that has no proposal in hand its next one; a proposal outside the prior box is a finished iteration
+  // as it stands — rejected without a solve and without a uniform (MCMC.py:318-322), sigma^2 updated, trace row written —
+  // so while some lane of the wave came out of bounds and tries are left, the wave closes those iterations and goes round
+  // again instead of taking them through a forward solve as idle lanes: with the proposal as wide as the reference's own
+  // main.py leaves it (list prior: never adapted, MCMC.py:524-527) four proposals in ten are out of bounds, and a lane
+  // that ran ahead this way does a solve's worth of work in every solve.  Lanes that already hold an in-bounds proposal
+  // wait out those short rounds.  Nothing about a chain changes: its variates are keyed by (chain, iteration), whichever
+  // round draws them.  With replayed variates, or with tables staged chunk by chunk behind workgroup barriers (every
+  // wave must then take the same number of solves), there is one try: one iteration per lane and round, as before round 4.
+  // The chain state loaded above is complete before the loop starts (the asm reads and redefines the registers): otherwise
+  // the loads stay "pending" on the loop's no-solve path as far as the compiler's wait-count bookkeeping can tell, and it
+  // guards the first use of sigma^2 and SSq in every round with a wait for ALL vector memory — which at run time is the
+  // trace row stored a few instructions earlier (stores and loads share the counter): a store's round trip per round.
+#pragma unroll
+  for (int p = 0; p < D; ++p) asm volatile("" : "+v"(q[p]));
+  asm volatile("" : "+v"(ssq), "+v"(std2), "+v"(V1));
+  const int32_t n_iters = (int32_t)A.n_iters;
+  const int max_tries = (REPLAY || !resident) ? 1 : kProposalTries;
+  int32_t nl = valid ? 0 : n_iters;
+  int32_t to_adapt = A.adapt_interval - (int32_t)(A.iter_base % A.adapt_interval);  // closes until the next adaptation is due
+  bool have = false;  // an in-bounds proposal (qn, lu, thr) waits for the solve
+  double qn[D], lu = 0.0, thr = INFINITY;
+#pragma unroll
+  for (int p = 0; p < D; ++p) qn[p] = 1.0;
+  int tries = 0;
+  for (int32_t round = 0;; ++round) {
+    const bool todo = nl < n_iters;
+    if (resident ? !__any(todo) : round == n_iters) break;
+    const uint32_t it = (uint32_t)(A.iter_base + nl);
+    // the lane's offset as this round sees it: opaque, so that the addresses built from it are formed where they are
     // used instead of being hoisted out of the loop and kept (or spilled) across every forward solve
     unsigned tl = t;
     asm volatile("" : "+v"(tl));
+    const uint64_t gid = (uint64_t)(A.chain_offset + blk + tl);  // RNG is keyed by the GLOBAL chain id
+    const int64_t row = (int64_t)nl * A.C + blk + tl;  // this lane's row of the traces / replayed variates
     // ---- proposal, MCMC.py:497 ----
-    double z[4] = {0.0, 0.0, 0.0, 0.0};
-    if (REPLAY) {
-      if (valid) {
-#pragma unroll
-        for (int p = 0; p < D; ++p) z[p] = (A.z + row0 * D)[tl * D + p];
-      }
-    } else {
-      uint32_t w[4];
-      rsf::draw_words(A.seed, gid, it, rsf::SLOT_Z01, w);
-      rsf::normal_pair(w, z[0], z[1]);
-      if (D > 2) {
-        rsf::draw_words(A.seed, gid, it, rsf::SLOT_Z2, w);
-        rsf::normal_pair(w, z[2], z[3]);
-      }
-    }
-    double qn[D];
-    if constexpr (D == 1) {
-      double Lc;
-      rsf::chol_lower<1>(&V1, &Lc);  // sqrt(V), or 0 where V is not positive
-      propose<1>(q, [&](int) { return Lc; }, z, qn);
-    } else {
-      propose<D>(q, [&](int e) { return lcs[e * blockDim.x]; }, z, qn);
-    }
-    const bool inb = valid && in_box<D>(qn, A.lo, A.hi);
-    // The chain's current point, sigma^2, SSq and the logarithm of the accept test's uniform wait out the forward solve in LDS
-    // (per-lane slots behind the table chunk; D = 3: behind the Cholesky factor's six) instead of in registers the
-    // integrator needs — the spills per proposal these kernels had otherwise.
-    constexpr bool kPark = MODE == RK4_F64;  // (the DOP853 kernel allocates worse with it: measured, tools/one_kernel.sh)
-    constexpr int kSlotQ = D == 3 ? 6 : 0, kSlotStd2 = kSlotQ + D, kSlotSsq = kSlotStd2 + 1, kSlotLu = kSlotSsq + 1;
-    static_assert(kSlotLu + 1 == kParkSlots<D>, "rsf_hip.hip sizes the launch's LDS with kParkSlots");
-    // ---- the accept test's uniform, drawn before the solve: with it the largest sum of squares that could still be
-    // accepted is known, and a lane whose running sum passes it stops holding its wave (rsf::Wave).  thr is that bound
-    // widened by 1e-9 (rounding in the test itself is ~1e-16): a lane inside the margin simply integrates to the end.
-    double lu = 0.0, thr = INFINITY;
-    if (inb) {
-      double u;
+    if (todo && !have) {
+      double z[4] = {0.0, 0.0, 0.0, 0.0};
       if (REPLAY) {
-        u = (A.u + row0)[tl];
+#pragma unroll
+        for (int p = 0; p < D; ++p) z[p] = A.z[row * D + p];
       } else {
         uint32_t w[4];
-        rsf::draw_words(A.seed, gid, it, rsf::SLOT_U, w);
-        u = rsf::u53(w[0], w[1]);
+        rsf::draw_words(A.seed, gid, it, rsf::SLOT_Z01, w);
+        rsf::normal_pair(w, z[0], z[1]);
+        if (D > 2) {
+          rsf::draw_words(A.seed, gid, it, rsf::SLOT_Z2, w);
+          rsf::normal_pair(w, z[2], z[3]);
+        }
       }
-      // (replaying recorded variates follows the reference's arithmetic to the last bit: IEEE division, libm-grade log;
-      //  the sampler proper uses the kernel's own reciprocal and log — the same value to ~1 ulp)
-      lu = REPLAY ? log(u) : rsf::rng_log(u);
-      if constexpr (MODE == RK4_F64 && !INJECT) {
-        const double t0 = __builtin_fma(-2.0 * std2, lu, ssq);  // accept iff ssqn < ssq - 2 std2 log u, MCMC.py:327-331
-        thr = __builtin_fma(1e-9, __builtin_fabs(t0), t0);       // NaN (a chain whose state is not finite): never stops early
-      }
-    }
-    if constexpr (kPark) {
-#pragma unroll
-      for (int p = 0; p < D; ++p) lcs[(kSlotQ + p) * blockDim.x] = q[p];
-      lcs[kSlotStd2 * blockDim.x] = std2;
-      lcs[kSlotSsq * blockDim.x] = ssq;
-      lcs[kSlotLu * blockDim.x] = lu;
-    }
-    // ---- likelihood: forward solve only for in-bounds proposals, MCMC.py:322-324 ----
-    double an = K.a_def, bn = K.b_def;
-    if constexpr (D == 3) { an = qn[1]; bn = qn[2]; }
-    double ssqn = 0.0;
-    const unsigned long long inbmask = rsf::ballot(inb);
-    cnt.evaluated += (uint32_t)__builtin_popcountll(inbmask);
-    cnt.oob += (uint32_t)__builtin_popcountll(rsf::ballot(valid && !inb));
-    // (a wave with no in-bounds lane skips the solve when the tables are resident: no barrier inside)
-    if constexpr (INJECT) {
-      if (inb) ssqn = (A.ssq_new + row0)[tl];
-    } else if (!resident || inbmask != 0) {
-      if constexpr (MODE == DOP853) {
-        ssqn = rsf::dp::solve<DAMP, true, false>(lds, K, resident, inb, qn[0], an, bn, nullptr, 0);
+      if constexpr (D == 1) {
+        double Lc;
+        rsf::chol_lower<1>(&V1, &Lc);  // sqrt(V), or 0 where V is not positive
+        propose<1>(q, [&](int) { return Lc; }, z, qn);
       } else {
-        ssqn = rsf::solve<DAMP, true, false, (D == 1 ? 2 : kD3Trip) * rsf::kTightUnroll>(lds, K, resident, inb, qn[0], an, bn, thr, nullptr, 0, cnt.W);
-        cnt.early += (uint32_t)__builtin_popcountll(inbmask & ~cnt.W.alive);
+        propose<D>(q, [&](int e) { return lcs[e * blockDim.x]; }, z, qn);
+      }
+      have = in_box<D>(qn, A);
+      // ---- the accept test's uniform, drawn before the solve: with it the largest sum of squares that could still be
+      // accepted is known, and a lane whose running sum passes it stops holding its wave (rsf::Wave).  thr is that bound
+      // widened by 1e-9 (rounding in the test itself is ~1e-16): a lane inside the margin simply integrates to the end.
+      lu = 0.0;
+      thr = INFINITY;
+      if (have) {
+        double u;
+        if (REPLAY) {
+          u = A.u[row];
+        } else {
+          uint32_t w[4];
+          rsf::draw_words(A.seed, gid, it, rsf::SLOT_U, w);
+          u = rsf::u53(w[0], w[1]);
+        }
+        // (replaying recorded variates follows the reference's arithmetic to the last bit: IEEE division, libm-grade log;
+        //  the sampler proper uses the kernel's own reciprocal and log — the same value to ~1 ulp)
+        lu = REPLAY ? log(u) : rsf::rng_log(u);
+        if constexpr (MODE == RK4_F64 && !INJECT) {
+          const double t0 = __builtin_fma(-2.0 * std2, lu, ssq);  // accept iff ssqn < ssq - 2 std2 log u, MCMC.py:327-331
+          thr = __builtin_fma(1e-9, __builtin_fabs(t0), t0);       // NaN (a chain whose state is not finite): never stops early
+        }
       }
     }
-    if (inbmask != 0) ++cnt.wave_solves;
-    else ++cnt.wave_skips;
-    if constexpr (kPark) {
-      const double *back = lcs;
-      asm volatile("" : "+v"(back));  // opaque: the values are re-read, not carried across the solve
+    const bool oob = todo && !have;  // this lane's iteration is finished without a solve
+    // solve now, unless a lane that just closed an out-of-bounds iteration can still come back with a proposal
+    const bool solve_now = tries + 1 >= max_tries || !__any(oob);
+    tries = solve_now ? 0 : tries + 1;
+    double ssqn = 0.0;
+    if (solve_now) {
+      const unsigned long long inbmask = rsf::ballot(have);
+      cnt.evaluated += (uint32_t)__builtin_popcountll(inbmask);
+      if (inbmask != 0) ++cnt.wave_solves;
+      else ++cnt.wave_skips;
+      if constexpr (kPark) {
 #pragma unroll
-      for (int p = 0; p < D; ++p) q[p] = back[(kSlotQ + p) * blockDim.x];
-      std2 = back[kSlotStd2 * blockDim.x];
-      ssq = back[kSlotSsq * blockDim.x];
-      lu = back[kSlotLu * blockDim.x];
+        for (int p = 0; p < D; ++p) lcs[(kSlotQ + p) * blockDim.x] = q[p];
+        lcs[kSlotStd2 * blockDim.x] = std2;
+        lcs[kSlotSsq * blockDim.x] = ssq;
+        lcs[kSlotLu * blockDim.x] = lu;
+      }
+      // ---- likelihood: forward solve only for in-bounds proposals, MCMC.py:322-324 ----
+      double an = K.a_def, bn = K.b_def;
+      if constexpr (D == 3) { an = qn[1]; bn = qn[2]; }
+      // (a wave with no in-bounds lane skips the solve when the tables are resident: no barrier inside)
+      if constexpr (INJECT) {
+        if (have) ssqn = A.ssq_new[row];
+      } else if (!resident || inbmask != 0) {
+        if constexpr (MODE == DOP853) {
+          ssqn = rsf::dp::solve<DAMP, true, false>(lds, K, resident, have, qn[0], an, bn, nullptr, 0);
+        } else {
+          ssqn = rsf::solve<DAMP, true, false, (D == 1 ? 2 : kD3Trip) * rsf::kTightUnroll>(lds, K, resident, have, qn[0], an, bn, thr, nullptr, 0, cnt.W);
+          cnt.early += (uint32_t)__builtin_popcountll(inbmask & ~cnt.W.alive);
+        }
+      }
+      if constexpr (kPark) {
+        // opaque: the values are re-read, not carried across the solve.  The OFFSET is laundered, not the pointer: a pointer
+        // that went through the asm has lost its address space and is read back with flat loads, which sit on the
+        // vector-memory counter too — the wait for them then also waits for the trace row stored just before.
+        unsigned relaunder = 0;
+        asm volatile("" : "+v"(relaunder));
+        const double *back = lcs + relaunder;
+#pragma unroll
+        for (int p = 0; p < D; ++p) q[p] = back[(kSlotQ + p) * blockDim.x];
+        std2 = back[kSlotStd2 * blockDim.x];
+        ssq = back[kSlotSsq * blockDim.x];
+        lu = back[kSlotLu * blockDim.x];
+      }
     }
-    // ---- accept / reject, MCMC.py:327-333 ----
+    // ---- close the iteration: of the lanes that were solved, and of the lanes whose proposal was out of bounds ----
+    const bool solved = solve_now && have;
+    // accept / reject, MCMC.py:327-333
     bool accept = false;
-    if (inb) {
+    if (solved) {
       accept = accept_test(REPLAY ? 0.5 * (ssq - ssqn) / std2 : (0.5 * (ssq - ssqn)) * rsf::fm::rcp(std2), lu);
       if (accept) {
         ssq = ssqn;
@@ -588,59 +636,63 @@ __global__ void __launch_bounds__(kMaxBlock, kMinBlocks) mcmc_kernel(Consts K, M
       }
     }
     cnt.accepted += (uint32_t)__builtin_popcountll(rsf::ballot(accept));
-    cnt.nonfinite += (uint32_t)__builtin_popcountll(rsf::ballot(inb && !isfinite(ssqn)));
-    // ---- sigma^2 Gibbs update with the post-accept SSq, MCMC.py:158-160 ----
-    if (valid) {
+    cnt.nonfinite += (uint32_t)__builtin_popcountll(rsf::ballot(solved && !isfinite(ssqn)));
+    cnt.oob += (uint32_t)__builtin_popcountll(rsf::ballot(oob));
+    if (solved || oob) {
+      // sigma^2 Gibbs update with the post-accept SSq, MCMC.py:158-160
       const double bval = 0.5 * (A.n0 * std2 + ssq);
-      const double g = REPLAY ? (A.g + row0)[tl] : rsf::gamma_draw(A.seed, gid, it, A.gd, A.gc);
+      const double g = REPLAY ? A.g[row] : rsf::gamma_draw(A.seed, gid, it, A.gd, A.gc);
       std2 = REPLAY ? bval / g : bval * rsf::fm::rcp(g);
       if (A.tq) {
 #pragma unroll
-        for (int p = 0; p < D; ++p) (A.tq + row0 * D)[tl * D + p] = q[p];
+        for (int p = 0; p < D; ++p) A.tq[row * D + p] = q[p];
       }
-      if (A.ts) (A.ts + row0)[tl] = std2;
-      if (A.ta) (A.ta + row0)[tl] = accept ? 1 : 0;
-    }
-    // ---- adaptation, MCMC.py:200-204, 523-527 ----
-    if (A.adapt_mode != RSF_ADAPT_NONE && valid) {
-      if (!kWinRegs) load_window(tl);
+      if (A.ts) A.ts[row] = std2;
+      if (A.ta) A.ta[row] = accept ? 1 : 0;
+      // adaptation, MCMC.py:200-204, 523-527
+      if (A.adapt_mode != RSF_ADAPT_NONE) {
+        if (!kWinRegs) load_window(tl);
 #pragma unroll
-      for (int p = 0; p < D; ++p) {
-        ws[p] += q[p] - wr[p];
+        for (int p = 0; p < D; ++p) {
+          ws[p] += q[p] - wr[p];
 #pragma unroll
-        for (int r = 0; r < D; ++r) wq[p * D + r] += (q[p] - wr[p]) * (q[r] - wr[r]);
-      }
-      ++wn;
-      if (A.adapt_mode == RSF_ADAPT_REFERENCE_DICT) at(A.wbuf, (int)((A.iter_base + n) % A.adapt_interval))[tl] = q[0];
-      if ((A.iter_base + n + 1) % A.adapt_interval == 0) {
-        if (wn >= 2) {
-          const double nn = (double)wn;
-          double Vn[D * D], Ln[D * D];
-          if (A.adapt_mode == RSF_ADAPT_REFERENCE_DICT) {
-            // d := len(qpriors.keys()) (2 for {1: lo, 2: hi}), and the Cholesky FACTOR becomes the next covariance
-            // (one-parameter chains only: rsf_mcmc_init refuses the mode for D = 3).  The window's covariance in np.cov's own
-            // arithmetic, from the samples kept in wbuf (full and in order whenever an adaptation is due).
-            Vn[0] = A.dict_scale * rsf::np_cov_1d([&](int k) { return at(A.wbuf, k)[tl]; }, A.adapt_interval);
-            if (rsf::chol_lower<1>(Vn, Ln)) V1 = Ln[0];
-          } else if (rsf::window_covariance<D>(ws, wq, nn, 2.38 * 2.38 / (double)D, Vn, Ln)) {
-            if constexpr (D == 1) {
-              V1 = Vn[0];
-            } else {
+          for (int r = 0; r < D; ++r) wq[p * D + r] += (q[p] - wr[p]) * (q[r] - wr[r]);
+        }
+        ++wn;
+        if (A.adapt_mode == RSF_ADAPT_REFERENCE_DICT) at(A.wbuf, A.adapt_interval - to_adapt)[tl] = q[0];  // slot (iteration % interval)
+        if (--to_adapt == 0) {
+          to_adapt = A.adapt_interval;
+          if (wn >= 2) {
+            const double nn = (double)wn;
+            double Vn[D * D], Ln[D * D];
+            if (A.adapt_mode == RSF_ADAPT_REFERENCE_DICT) {
+              // d := len(qpriors.keys()) (2 for {1: lo, 2: hi}), and the Cholesky FACTOR becomes the next covariance
+              // (one-parameter chains only: rsf_mcmc_init refuses the mode for D = 3).  The window's covariance in np.cov's own
+              // arithmetic, from the samples kept in wbuf (full and in order whenever an adaptation is due).
+              Vn[0] = A.dict_scale * rsf::np_cov_1d([&](int k) { return at(A.wbuf, k)[tl]; }, A.adapt_interval);
+              if (rsf::chol_lower<1>(Vn, Ln)) V1 = Ln[0];
+            } else if (rsf::window_covariance<D>(ws, wq, nn, 2.38 * 2.38 / (double)D, Vn, Ln)) {
+              if constexpr (D == 1) {
+                V1 = Vn[0];
+              } else {
 #pragma unroll
-              for (int e = 0; e < D * D; ++e) at(A.V, e)[tl] = Vn[e];
-              store_factor(Ln);
+                for (int e = 0; e < D * D; ++e) at(A.V, e)[tl] = Vn[e];
+                store_factor(Ln);
+              }
             }
           }
+          wn = 0;
+#pragma unroll
+          for (int p = 0; p < D; ++p) { wr[p] = q[p]; ws[p] = 0.0; }
+#pragma unroll
+          for (int e = 0; e < D * D; ++e) wq[e] = 0.0;
         }
-        wn = 0;
-#pragma unroll
-        for (int p = 0; p < D; ++p) { wr[p] = q[p]; ws[p] = 0.0; }
-#pragma unroll
-        for (int e = 0; e < D * D; ++e) wq[e] = 0.0;
+        if (!kWinRegs) store_window(tl);
       }
-      if (!kWinRegs) store_window(tl);
+      ++nl;
+      have = false;
     }
-    if ((n & (kFlushEvery - 1)) == kFlushEvery - 1) cnt.flush(A.stats);
+    if ((round & (kFlushEvery - 1)) == kFlushEvery - 1) cnt.flush(A.stats);
   }
 
   if (valid) {
@@ -683,7 +735,7 @@ __global__ void __launch_bounds__(kMaxBlock) propose_kernel(ProposeArgs A) {
   propose<D>(q, [&](int k) { return tri[k]; }, z, qn);
 #pragma unroll
   for (int p = 0; p < D; ++p) A.qn[i * D + p] = qn[p];
-  A.inb[i] = in_box<D>(qn, A.lo, A.hi) ? 1 : 0;
+  A.inb[i] = in_box<D>(qn, A) ? 1 : 0;
 }
 
 // The float32 sampler (RSF_FLAG_FP32_SOLVE): the same iteration as mcmc_kernel, with TWO chains per lane, because its

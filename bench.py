@@ -342,7 +342,7 @@ def time_sampler(pkg, model, data, C, ips, steps, warmup, rank, barrier, d=1):
     barrier()
     wall = time.perf_counter() - t0
     kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
-    return wall, kernel_ms, eng.stats(), eng, traces, nout
+    return wall, kernel_ms, dict(eng.stats(), counters=eng.counters()), eng, traces, nout
 
 
 def roofline_views(workload, custom, C, ips, nout, stats, kernel_ms, d=1, mode="RK4", build_id=None):
@@ -488,7 +488,16 @@ def main():
                        "chains_per_gpu": C, "nsteps": nsteps, "rk4_substeps": 1, "proposals_per_chain_per_step": ips,
                        "n_params": d, "adapt_mode": "none", "integrator": args.integrator, "parallelism": f"chains sharded over {world} GPU(s), no data-path collective",
                        "evaluated_fraction": evaluated,
-                       "acceptance": stats["accepted"] / max(1, stats["iters_done"] * C)},
+                       "acceptance": stats["accepted"] / max(1, stats["iters_done"] * C),
+                       # where the wave-steps went (rsf_mcmc_counters, float64 RK4 sampler): in-bounds proposals whose solve was cut
+                       # short because their running sum of squares already ruled acceptance out (exact: partial sums of squares
+                       # only grow); share of lane-steps on lanes still integrating; wave-steps per tier.  In this workload every
+                       # wave keeps an undecided lane to the end of the series: no wave-step is skipped, value counts executed work
+                       "early_rejected_of_evaluated": stats["counters"]["early_rejected"] / max(1, stats["counters"]["evaluated"]),
+                       "lane_utilisation": stats["counters"]["lane_utilisation"],
+                       "wave_steps_vs_full_series": (sum(stats["counters"]["steps_" + t] for t in ("tight", "narrow", "wide", "full"))
+                                                     / max(1, stats["counters"]["wave_solves"] * (nout - 1))) if mode == "RK4" else None,
+                       "tier_wave_steps": {t: stats["counters"]["steps_" + t] for t in ("tight", "narrow", "wide", "full")}},
             "roofline": valu, "roofline_hbm": hbm,
         }
         out["previous_round"] = previous_round_line(out["config"]["workload"], value)

@@ -39,7 +39,12 @@ def main():
     libs = {"default": pkg._abi.load()}
     for v in args.variants:
         name, path = v.split("=", 1)
-        libs[name] = pkg._abi.bind(ctypes.CDLL(os.path.abspath(path)))
+        lib = ctypes.CDLL(os.path.abspath(path))
+        for sym, (restype, argtypes) in pkg._abi.PROTOTYPES.items():  # an older build is bound with the symbols it has
+            if hasattr(lib, sym):
+                getattr(lib, sym).restype, getattr(lib, sym).argtypes = restype, argtypes
+        assert lib.rsf_backend() == b"hip-gfx950", path
+        libs[name] = lib
     model, data = synthetic_problem(args.nsteps)
     model.precision = args.precision
     model.integrator = args.integrator
