@@ -60,7 +60,14 @@ class MCMC:
         self.data = data
         self.lstm_model = lstm_model
         self.n0 = 0.01
-        self.qstart_limits = np.array([[self.qpriors[1], self.qpriors[2]]])
+        if self._multi_parameter():
+            # additive (BASELINE config 5): joint (Dc, a, b) — one ["Uniform", lo, hi] spec per parameter, qstart a 3-vector.  The
+            # reference's sampler has one parameter (MCMC.py:98, 381); the three-parameter chains run through sample_batched only.
+            if len(self.qpriors) != 3 or np.size(self.qstart) != 3:
+                raise ValueError("joint inference takes three prior specs [[name, lo, hi]] x 3 for (Dc, a, b) and a 3-vector qstart")
+            self.qstart_limits = np.array([[p[1], p[2]] for p in self.qpriors], dtype=np.float64)
+        else:
+            self.qstart_limits = np.array([[self.qpriors[1], self.qpriors[2]]])
         self.dc_true = dc_true
         # additive: consume the N normals each reference forward solve wastes (RateStateModel.py:392)
         self.replay_reference_rng = True
@@ -84,16 +91,34 @@ class MCMC:
     def _prior_is_dict(self):
         return hasattr(self.qpriors, "keys")
 
+    def _multi_parameter(self):
+        """Three prior specs, one per parameter of (Dc, a, b), instead of the reference's single ["Uniform", lo, hi]."""
+        try:
+            first = self.qpriors[0]
+        except (KeyError, IndexError, TypeError):
+            return False
+        return not isinstance(first, (str, bytes)) and np.ndim(first) == 1 and len(first) == 3
+
+    @property
+    def n_params(self):
+        return 3 if self._multi_parameter() else 1
+
     def _adapt_mode(self):
-        # list prior: update_covariance_matrix raises AttributeError, swallowed at MCMC.py:524-527 => never adapts
+        # list prior: update_covariance_matrix raises AttributeError, swallowed at MCMC.py:524-527 => never adapts.
+        # Three parameters (this build's extension): corrected adaptive Metropolis — the initial proposal follows the (Dc, a)
+        # ridge only locally, and what the chains learn about it is what makes them mix (SURVEY §8f row 1)
+        if self._multi_parameter():
+            return "am"
         return "reference_dict" if self._prior_is_dict() else "none"
 
     def _init_chains(self, eng, q0, seed=0, chain_offset=0, adapt_mode=None):
         data = np.ascontiguousarray(self.data, dtype=np.float64).reshape(-1)
         lo, hi = self.qstart_limits[:, 0], self.qstart_limits[:, 1]
+        # forward-difference step of the initial sensitivities: the reference's 1e-6 for its one parameter (MCMC.py:251); 1e-4 for
+        # the three-parameter extension, whose regularised covariance does not need the small step and is cleaner without it
         eng.mcmc_init(q0, data, lo, hi, seed=seed, chain_offset=chain_offset, n0=self.n0,
                       prior_len=len(self.qpriors), adapt_mode=adapt_mode or self._adapt_mode(),
-                      adapt_interval=self.adapt_interval)
+                      adapt_interval=self.adapt_interval, fd_rel_step=1e-4 if self._multi_parameter() else 1e-6)
 
     # ---- reference sub-methods (public names kept; each one runs its step on the device) -----------------------
     # A caller that composes them the way the reference's own loop does (MCMC.py:494-527) gets the arithmetic of the fused
@@ -213,6 +238,9 @@ class MCMC:
     # ---- the hot loop -------------------------------------------------------------------
     def sample(self, MAKE_ANIMATIONS=False):
         """One chain, nsamples proposals → ndarray (1, nsamples + 1 - nburn)  (MCMC.py:391-544)."""
+        if self._multi_parameter():
+            raise NotImplementedError("sample() is the reference's one-parameter loop (MCMC.py:98, 381); joint (Dc, a, b) chains run "
+                                      "through sample_batched")
         eng = self._engine()
         if not self._device_model():
             return self._sample_host_model(eng, MAKE_ANIMATIONS)
@@ -316,11 +344,20 @@ class MCMC:
         n_iters = self.nsamples if n_iters is None else n_iters
         nburn = int(n_iters / 2) if keep == "post_burn" else 0
         gids = chain_offset + np.arange(n_chains)
+        d = self.n_params
         if q0 is None:
-            q0 = np.full((n_chains, 1), float(self.qstart))
-            if jitter is not None:
-                q0[:, 0] = [np.random.default_rng([seed, int(g)]).uniform(*jitter) for g in gids]
+            q0 = np.tile(np.asarray(self.qstart, dtype=np.float64).reshape(1, d), (n_chains, 1))
+            if jitter is not None:  # (lo, hi) for Dc, or one (lo, hi) per parameter: start points spread over that box
+                jit = np.broadcast_to(np.asarray(jitter, dtype=np.float64).reshape(-1, 2), (d, 2)) if np.ndim(jitter) > 1 else None
+                for r, g in enumerate(gids):
+                    rng = np.random.default_rng([seed, int(g)])
+                    if jit is None:
+                        q0[r, 0] = rng.uniform(*jitter)
+                    else:
+                        q0[r] = rng.uniform(jit[:, 0], jit[:, 1])
         q0 = np.asarray(q0, dtype=np.float64).reshape(n_chains, -1)
+        if q0.shape[1] != d:
+            raise ValueError(f"q0 has {q0.shape[1]} columns, the sampler {d} parameter(s)")
         if not self._device_model():
             raise TypeError("sample_batched integrates the model on the device: `model` must be this package's RateStateModel "
                             "(sample() takes any model object with .Dc and .evaluate())")

@@ -768,15 +768,22 @@ __device__ __forceinline__ void sym_inverse(const double *A, double *Ai) {
   }
 }
 
-// update_covariance_matrix, MCMC.py:200-204: scale * np.cov(window) (ddof = 1) from the window's shifted sums
-// ws[p] = sum (q_p - ref_p), wq[p][r] = sum (q_p - ref_p)(q_r - ref_r) over nn samples, and its lower Cholesky factor.
-// false: not positive definite (np.linalg.cholesky raises, the caller keeps its covariance, MCMC.py:524-527).
+// scale * (cov + diag(eps)) from shifted sums ws[p] = sum (q_p - ref_p), wq[p][r] = sum (q_p - ref_p)(q_r - ref_r) over nn
+// samples (ddof = 1, like np.cov), and its lower Cholesky factor.  false: not positive definite (the caller keeps its
+// covariance; with eps > 0 that does not happen).  This is the corrected adaptive Metropolis of `adapt_mode = am`
+// (Haario, Saksman & Tamminen 2001): the sums run over the chain's WHOLE history since rsf_mcmc_init — adaptation that
+// diminishes, so the chain still converges to the posterior — and eps_p = (1e-6 (hi_p - lo_p))^2 keeps the matrix positive
+// definite when the history holds fewer than D + 1 distinct points.  (Until round 4 `am` used the last adapt_interval samples
+// only, as the reference's broken update does: measured on the three-parameter problem, that shifts the pooled posterior —
+// the mean of Dc*a by 89 standard errors, its spread by 8 % — because a proposal that forgets is a different chain, not an
+// adaptive one; and a window with too few distinct points made "positive definite" a coin toss of the last bit.)
 template <int D>
-__device__ __forceinline__ bool window_covariance(const double *ws, const double *wq, double nn, double scale, double *Vn, double *Ln) {
+__device__ __forceinline__ bool window_covariance(const double *ws, const double *wq, double nn, double scale, const double *eps, double *Vn,
+                                                  double *Ln) {
 #pragma unroll
   for (int p = 0; p < D; ++p)
 #pragma unroll
-    for (int r = 0; r < D; ++r) Vn[p * D + r] = scale * ((wq[p * D + r] - ws[p] * ws[r] / nn) / (nn - 1.0));
+    for (int r = 0; r < D; ++r) Vn[p * D + r] = scale * ((wq[p * D + r] - ws[p] * ws[r] / nn) / (nn - 1.0) + (p == r ? eps[p] : 0.0));
   return chol_lower<D>(Vn, Ln);
 }
 

@@ -412,7 +412,11 @@ int run_mcmc(rsf_ctx *c, int64_t n_iters, const double *z, const double *u, cons
   A.C = C; A.chain_offset = c->mc.chain_offset; A.n_iters = n_iters; A.iter_base = c->iters_done;
   A.seed = c->mc.seed; A.n0 = c->mc.n0; A.shape = 0.5 * (c->mc.n0 + (double)c->nout);  // MCMC.py:158
   A.gd = A.shape - 1.0 / 3.0; A.gc = 1.0 / std::sqrt(9.0 * A.gd);
-  for (int p = 0; p < RSF_MAX_PARAMS; ++p) { A.lo[p] = c->mc.lo[p]; A.hi[p] = c->mc.hi[p]; }
+  for (int p = 0; p < RSF_MAX_PARAMS; ++p) {
+    A.lo[p] = c->mc.lo[p]; A.hi[p] = c->mc.hi[p];
+    const double w = 1e-6 * (c->mc.hi[p] - c->mc.lo[p]);
+    A.am_eps[p] = w * w;
+  }
   A.adapt_mode = c->mc.adapt_mode; A.adapt_interval = c->mc.adapt_interval > 0 ? c->mc.adapt_interval : 1;
   A.dict_scale = 2.38 * 2.38 / (double)(c->mc.prior_len > 0 ? c->mc.prior_len : 2);
   A.lc_off = (int32_t)(mcmc_table_bytes(c) / sizeof(double));
@@ -760,6 +764,7 @@ int rsf_mcmc_init(rsf_ctx *c, const rsf_mcmc_config *cfg, const double *q0, cons
   A.C = C;
   A.fd = cfg->fd_rel_step;
   A.inv_dof = 1.0 / (double)(c->nout - (cfg->prior_len ? cfg->prior_len : d));
+  for (int p = 0; p < RSF_MAX_PARAMS; ++p) A.width[p] = cfg->hi[p] - cfg->lo[p];
   A.q0 = (const double *)c->q.p;
   A.ssq = (double *)c->ssq.p; A.std2 = (double *)c->std2.p; A.V = (double *)c->V.p;
   c->group_chains = G > 1 ? C / G : 0;

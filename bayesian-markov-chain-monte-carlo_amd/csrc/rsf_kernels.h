@@ -86,9 +86,40 @@ struct InitArgs {
   int64_t C;
   double fd;       // forward-difference relative step, MCMC.py:251
   double inv_dof;  // 1 / (nout - len(qpriors)), MCMC.py:261
+  double width[RSF_MAX_PARAMS];  // hi - lo of the prior box (three-parameter chains: initial_covariance)
   const double *q0;  // [d][C]
   double *ssq, *std2, *V;  // [C], [C], [d*d][C]
 };
+
+// The initial proposal covariance from the sensitivities' Gram matrix X^T X and sigma^2_0.
+// One parameter — the reference's sampler: Vstart = sigma^2 (X^T X)^-1, MCMC.py:265-266, as it stands.
+// Three parameters (Dc, a, b) — this build's extension (BASELINE config 5), where that formula does not give a proposal:
+// the series depends on Dc and a almost only through their product (relative sensitivities equal to five digits, correlation
+// eigenvalue 2e-11) and hardly at all on b (3000 times smaller), so (X^T X)^-1 is astronomically wide along a ridge — and
+// what little it says there is forward-difference rounding.  The data do not identify those directions; the PRIOR does.  So
+// the box prior enters the way a Gaussian of the same variance would, in coordinates u_p = (q_p - lo_p) / w_p that make the box a
+// unit cube:        M = W (X^T X) W / sigma^2 + 12 I,      V = W M^-1 W,      W = diag(w_p = hi_p - lo_p)
+// (a uniform variable on a unit interval has variance 1/12).  M is symmetric positive definite with every eigenvalue >= 12
+// (condition number ~4e3 at the BASELINE problem): no guard, no fallback.  Identified directions get their Gauss-Newton
+// width, unidentified ones the width of the box.
+template <int D>
+__device__ __forceinline__ void initial_covariance(const double *xtx, double std2, const double *width, double *V) {
+  if constexpr (D == 1) {
+    V[0] = std2 * (1.0 / xtx[0]);
+  } else {
+    double M[D * D], Mi[D * D];
+    const double is2 = 1.0 / std2;
+#pragma unroll
+    for (int p = 0; p < D; ++p)
+#pragma unroll
+      for (int r = 0; r < D; ++r) M[p * D + r] = (width[p] * xtx[p * D + r] * width[r]) * is2 + (p == r ? 12.0 : 0.0);
+    rsf::sym_inverse<D>(M, Mi);
+#pragma unroll
+    for (int p = 0; p < D; ++p)
+#pragma unroll
+      for (int r = 0; r < D; ++r) V[p * D + r] = width[p] * Mi[p * D + r] * width[r];
+  }
+}
 
 // One trip of NU steps for the unperturbed trajectory and its D perturbed companions, each with its own lane constants
 template <int D, bool DAMP, int T, int NU>
@@ -232,10 +263,10 @@ __global__ void __launch_bounds__(kMaxBlock) init_kernel(Consts K, InitArgs A) {
   }
   if (active) {
     const double std2 = ssq * A.inv_dof;
-    double xi[D * D];
-    rsf::sym_inverse<D>(xtx, xi);
+    double V[D * D];
+    initial_covariance<D>(xtx, std2, A.width, V);
 #pragma unroll
-    for (int e = 0; e < D * D; ++e) A.V[e * A.C + i] = std2 * xi[e];  // MCMC.py:266
+    for (int e = 0; e < D * D; ++e) A.V[e * A.C + i] = V[e];  // MCMC.py:266
     A.std2[i] = std2;
     A.ssq[i] = ssq;
   }
@@ -305,10 +336,10 @@ __global__ void __launch_bounds__(kMaxBlock) init_dp_kernel(Consts K, InitArgs A
   }
   if (active) {
     const double std2 = ssq * A.inv_dof;
-    double xi[D * D];
-    rsf::sym_inverse<D>(xtx, xi);
+    double V[D * D];
+    initial_covariance<D>(xtx, std2, A.width, V);
 #pragma unroll
-    for (int e = 0; e < D * D; ++e) A.V[e * A.C + i] = std2 * xi[e];  // MCMC.py:266
+    for (int e = 0; e < D * D; ++e) A.V[e * A.C + i] = V[e];  // MCMC.py:266
     A.std2[i] = std2;
     A.ssq[i] = ssq;
   }
@@ -396,6 +427,7 @@ struct McmcArgs {
   int32_t adapt_mode, adapt_interval;
   int32_t lc_off;     // D = 3: offset (in doubles) of the per-lane Cholesky factors behind the table chunk in LDS
   double dict_scale;  // 2.38^2 / len(qpriors.keys()), MCMC.py:200 (reference_dict mode)
+  double am_eps[RSF_MAX_PARAMS];  // am mode: (1e-6 (hi - lo))^2 added to the history's variances (rsf::window_covariance)
   double *q, *ssq, *std2, *V;           // per-chain state: q[d][C], ssq[C], std2[C], V[d*d][C]
   double *wref, *wsum, *wsq;            // adaptation window (shifted sums): [d][C], [d][C], [d*d][C]
   int32_t *wn;
@@ -586,8 +618,10 @@ __global__ void __launch_bounds__(kMaxBlock, kMinBlocks) mcmc_kernel(Consts K, M
     if (solve_now) {
       const unsigned long long inbmask = rsf::ballot(have);
       cnt.evaluated += (uint32_t)__builtin_popcountll(inbmask);
-      if (inbmask != 0) ++cnt.wave_solves;
-      else ++cnt.wave_skips;
+      if constexpr (!INJECT) {  // (with supplied sums of squares there is no solve to count)
+        if (inbmask != 0) ++cnt.wave_solves;
+        else ++cnt.wave_skips;
+      }
       if constexpr (kPark) {
 #pragma unroll
         for (int p = 0; p < D; ++p) lcs[(kSlotQ + p) * blockDim.x] = q[p];
@@ -671,7 +705,7 @@ __global__ void __launch_bounds__(kMaxBlock, kMinBlocks) mcmc_kernel(Consts K, M
               // arithmetic, from the samples kept in wbuf (full and in order whenever an adaptation is due).
               Vn[0] = A.dict_scale * rsf::np_cov_1d([&](int k) { return at(A.wbuf, k)[tl]; }, A.adapt_interval);
               if (rsf::chol_lower<1>(Vn, Ln)) V1 = Ln[0];
-            } else if (rsf::window_covariance<D>(ws, wq, nn, 2.38 * 2.38 / (double)D, Vn, Ln)) {
+            } else if (rsf::window_covariance<D>(ws, wq, nn, 2.38 * 2.38 / (double)D, A.am_eps, Vn, Ln)) {
               if constexpr (D == 1) {
                 V1 = Vn[0];
               } else {
@@ -681,11 +715,7 @@ __global__ void __launch_bounds__(kMaxBlock, kMinBlocks) mcmc_kernel(Consts K, M
               }
             }
           }
-          wn = 0;
-#pragma unroll
-          for (int p = 0; p < D; ++p) { wr[p] = q[p]; ws[p] = 0.0; }
-#pragma unroll
-          for (int e = 0; e < D * D; ++e) wq[e] = 0.0;
+          // (am keeps its sums: the covariance of the whole history.  reference_dict forms its window from wbuf and ignores them.)
         }
         if (!kWinRegs) store_window(tl);
       }
@@ -946,7 +976,7 @@ __global__ void __launch_bounds__(kMaxBlock, kMinBlocks) mcmc_f32x2_kernel(Const
               // (one-parameter chains only: rsf_mcmc_init refuses the mode for D = 3); np.cov's own arithmetic (mcmc_kernel)
               Vn[0] = A.dict_scale * rsf::np_cov_1d([&](int k) { return at(A.wbuf, k, s)[tl]; }, A.adapt_interval);
               if (rsf::chol_lower<1>(Vn, Ln)) c.V1 = Ln[0];
-            } else if (rsf::window_covariance<D>(c.ws, c.wq, nn, 2.38 * 2.38 / (double)D, Vn, Ln)) {
+            } else if (rsf::window_covariance<D>(c.ws, c.wq, nn, 2.38 * 2.38 / (double)D, A.am_eps, Vn, Ln)) {
               if constexpr (D == 1) {
                 c.V1 = Vn[0];
               } else {
@@ -956,11 +986,7 @@ __global__ void __launch_bounds__(kMaxBlock, kMinBlocks) mcmc_f32x2_kernel(Const
               }
             }
           }
-          c.wn = 0;
-#pragma unroll
-          for (int p = 0; p < D; ++p) { c.wr[p] = c.q[p]; c.ws[p] = 0.0; }
-#pragma unroll
-          for (int e = 0; e < D * D; ++e) c.wq[e] = 0.0;
+          // (am keeps its sums: the covariance of the whole history; mcmc_kernel)
         }
         if (!kWinRegs) store_window(s, tl);
       }
@@ -1013,7 +1039,8 @@ __device__ void adapt_window(int n, const double *win, int mode, double dict_sca
     Vn[0] = ok ? dict_scale * rsf::np_cov_1d([&](int k) { return win[k * D]; }, n) : 0.0;
     ok = ok && rsf::chol_lower<1>(Vn, Ln);
   } else {
-    ok = ok && rsf::window_covariance<D>(ws, wq, (double)n, 2.38 * 2.38 / (double)D, Vn, Ln);
+    const double no_eps[3] = {0.0, 0.0, 0.0};  // the given samples alone: what the sampler computes once its history is these
+    ok = ok && rsf::window_covariance<D>(ws, wq, (double)n, 2.38 * 2.38 / (double)D, no_eps, Vn, Ln);
   }
 #pragma unroll
   for (int e = 0; e < D * D; ++e) out[e] = dict ? Ln[e] : Vn[e];

@@ -48,7 +48,6 @@ WORKLOADS = {
 }
 START = [1000.0, 0.011, 0.014]                 # chain start and prior box of the 3-parameter problem
 BOX_LO, BOX_HI = [0.0, 0.005, 0.005], [1.0e4, 0.02, 0.03]
-PROPOSAL_STD = [20.0, 1.0e-4, 1.0e-4]          # explicit proposal covariance for d = 3: (X^T X)^-1 is near-singular there
 FLOPS_PER_RK4_STEP = 152.0       # 4 RHS x 27 + RK4 combine 39 + observation/SSq 5
 PEAK_HBM_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 PEAK_FP64_VALU_TFLOPS = 78.6     # 256 CU x 4 SIMD x 16 fp64 FMA lanes x 2 flop x 2.4 GHz
@@ -325,9 +324,10 @@ def time_sampler(pkg, model, data, C, ips, steps, warmup, rank, barrier, d=1):
     eng = pkg.Engine(mem="device")
     nout = eng.set_model(model, 1)
     q0 = torch.tensor(START[:d], dtype=torch.float64, device="cuda").repeat(C, 1)
-    eng.mcmc_init(q0, data, BOX_LO[:d], BOX_HI[:d], seed=2025, chain_offset=rank * C, prior_len=3 if d == 1 else 0, adapt_mode="none")
-    if d > 1:
-        eng.set_state(V=torch.diag(torch.tensor(PROPOSAL_STD[:d], dtype=torch.float64, device="cuda") ** 2).repeat(C, 1, 1))
+    # one parameter: the reference's own mode (list prior: no adaptation); joint (Dc, a, b): the init kernel's prior-regularised
+    # proposal covariance and corrected adaptive Metropolis — the documented three-parameter workflow, nothing hand-set
+    eng.mcmc_init(q0, data, BOX_LO[:d], BOX_HI[:d], seed=2025, chain_offset=rank * C, prior_len=3, adapt_mode="none" if d == 1 else "am",
+                  adapt_interval=10 if d == 1 else 20, fd_rel_step=1e-6 if d == 1 else 1e-4)
     traces = (torch.empty((ips, C, d), dtype=torch.float64, device="cuda"),
               torch.empty((ips, C), dtype=torch.float64, device="cuda"), None)
     for _ in range(warmup):
@@ -486,7 +486,7 @@ def main():
             "data": "synthetic", "build_id": build_id,
             "config": {"workload": (wl["desc"] if not custom else f"custom: {C} chains x nsteps {nsteps}, fp64") + (f" [{mode}]" if mode != "RK4" else ""),
                        "chains_per_gpu": C, "nsteps": nsteps, "rk4_substeps": 1, "proposals_per_chain_per_step": ips,
-                       "n_params": d, "adapt_mode": "none", "integrator": args.integrator, "parallelism": f"chains sharded over {world} GPU(s), no data-path collective",
+                       "n_params": d, "adapt_mode": "none" if d == 1 else "am", "integrator": args.integrator, "parallelism": f"chains sharded over {world} GPU(s), no data-path collective",
                        "evaluated_fraction": evaluated,
                        "acceptance": stats["accepted"] / max(1, stats["iters_done"] * C),
                        # where the wave-steps went (rsf_mcmc_counters, float64 RK4 sampler): in-bounds proposals whose solve was cut

@@ -72,7 +72,8 @@ extern "C" {
 #define RSF_ADAPT_REFERENCE_DICT 1 /* dict prior: V <- chol(2.38^2/prior_len * np.cov(window)), then used AS covariance; np.cov in
                                       NumPy's own arithmetic (pairwise-summed mean), so that a window of identical samples
                                       fails or "succeeds" with a collapsed proposal exactly where the reference's does */
-#define RSF_ADAPT_AM 2             /* corrected adaptive Metropolis: V <- 2.38^2/d * cov(window) */
+#define RSF_ADAPT_AM 2             /* corrected adaptive Metropolis (Haario et al. 2001): every adapt_interval iterations
+                                      V <- 2.38^2/d * (cov(every sample since rsf_mcmc_init) + diag((1e-6 (hi - lo))^2)) */
 
 #define RSF_MAX_PARAMS 3
 #define RSF_DICT_MAX_INTERVAL 128 /* reference_dict adaptation keeps its window's samples: adapt_interval at most this (default 10) */
@@ -162,7 +163,10 @@ int rsf_forward_batch(rsf_ctx *ctx, int64_t n_lanes, const double *dc, const dou
 /* MCMC.__init__ + compute_initial_covariance + the initial SSqcalc (MCMC.py:464-468),
  * per chain: std2_0 = SSq(q0)/(nout - prior_len); Vstart = std2_0 * (X^T X)^-1 with X the
  * forward-difference sensitivity (perturbed-Dc denominator quirk kept, MCMC.py:251,264).
- * For d == 3 the sensitivity is taken per parameter (extension).
+ * For d == 3 (extension, BASELINE config 5) the sensitivity is taken per parameter and the box prior regularises the
+ * covariance: with W = diag(hi - lo), M = W X^T X W / std2_0 + 12 I and Vstart = W M^-1 W — (X^T X)^-1 alone is no proposal
+ * there, the series identifies Dc and a only through their product and b hardly at all; the prior supplies the rest, as a
+ * Gaussian of the box's variance would (1/12 per unit interval).  A larger fd_rel_step (1e-4) is advisable for d == 3.
  *   q0[C][d]              start point per chain
  *   data[n_groups][nout]  observation series (kept by the ctx); n_chains must be a multiple of n_groups and,
  *                         in the HIP library, n_chains/n_groups a multiple of the workgroup size */

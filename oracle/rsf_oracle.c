@@ -597,8 +597,22 @@ int rsf_mcmc_init(rsf_ctx *c, const rsf_mcmc_config *cfg, const double *q0, cons
           XtX[p * d + r] = s;
         }
       double std2 = s0 / (double)(N - plen);                 /* MCMC.py:261 */
-      sym_inverse(XtX, d, Xi);
-      for (int e = 0; e < d * d; ++e) c->V[i * d * d + e] = std2 * Xi[e]; /* MCMC.py:266 */
+      if (d == 1) {
+        sym_inverse(XtX, d, Xi);
+        c->V[i] = std2 * Xi[0];                              /* MCMC.py:265-266 */
+      } else {
+        /* Three parameters (this build's extension): the reference's formula has no usable answer — the series depends on Dc
+         * and a almost only through their product, hardly on b, so (X^T X)^-1 is astronomically wide along a ridge.  The box
+         * prior enters as a Gaussian of equal variance in unit-cube coordinates: M = W X^T X W / sigma^2 + 12 I, V = W M^-1 W,
+         * W = diag(hi - lo).  (csrc/rsf_kernels.h::initial_covariance has the full reasoning.) */
+        double M[9], Mi[9], w[3];
+        for (int p = 0; p < d; ++p) w[p] = cfg->hi[p] - cfg->lo[p];
+        for (int p = 0; p < d; ++p)
+          for (int r = 0; r < d; ++r) M[p * d + r] = (w[p] * XtX[p * d + r] * w[r]) * (1.0 / std2) + (p == r ? 12.0 : 0.0);
+        sym_inverse(M, d, Mi);
+        for (int p = 0; p < d; ++p)
+          for (int r = 0; r < d; ++r) c->V[i * d * d + p * d + r] = w[p] * Mi[p * d + r] * w[r];
+      }
       c->std2[i] = std2;
       c->ssq[i] = f32 ? solve(c, q[0], a, b, data_of(c, i), NULL, 0) : s0;
     }
@@ -753,13 +767,17 @@ static void run_chain(rsf_ctx *c, int64_t i, int64_t n_iters, const double *zs, 
             Vn[0] = 2.38 * 2.38 / (double)(mc->prior_len > 0 ? mc->prior_len : 2) * np_cov_1d(c->wbuf + i * mc->adapt_interval, mc->adapt_interval);
             if (chol_lower(Vn, 1, Ln)) V[0] = Ln[0];
           } else {
-            for (int e = 0; e < d * d; ++e) Vn[e] = 2.38 * 2.38 / (double)d * cov[e];
+            /* am: corrected adaptive Metropolis (Haario et al. 2001) — the covariance of the chain's WHOLE history (the sums are
+             * never reset: adaptation diminishes, the chain keeps the posterior as its limit) plus eps_p = (1e-6 (hi_p - lo_p))^2
+             * on the diagonal, which keeps it positive definite whatever the history holds */
+            for (int p = 0; p < d; ++p)
+              for (int r = 0; r < d; ++r) {
+                double w = 1e-6 * (mc->hi[p] - mc->lo[p]);
+                Vn[p * d + r] = 2.38 * 2.38 / (double)d * (cov[p * d + r] + (p == r ? w * w : 0.0));
+              }
             if (chol_lower(Vn, d, Ln)) memcpy(V, Vn, sizeof(double) * d * d);
           }
         }
-        c->wn[i] = 0;
-        for (int p = 0; p < d; ++p) { wr[p] = q[p]; ws[p] = 0.0; }
-        for (int e = 0; e < d * d; ++e) wq[e] = 0.0;
       }
     }
   }

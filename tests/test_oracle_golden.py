@@ -207,6 +207,69 @@ def test_likelihood_operator_replays_reference_exactly(cpu_engine, golden, tag):
         cpu_engine.mcmc_run(1)
 
 
+def test_three_parameter_initial_covariance(cpu_engine, oracle_mod):
+    """BASELINE config 5 (this build's extension; the reference infers Dc alone, MCMC.py:98, 381): the initial proposal for
+    joint (Dc, a, b).  sigma^2 (X^T X)^-1 alone is no proposal there — the series depends on Dc and a almost only through
+    their product and hardly on b — so the box prior regularises it: M = W X^T X W / sigma^2 + 12 I, V = W M^-1 W.  Checked
+    on the checker: the formula itself from independently computed sensitivities; V follows the (Dc, a) ridge (correlation
+    ~ -0.99), is prior-wide in b, never wider than the prior anywhere, and does not depend on the forward-difference step."""
+    from conftest import synthetic_data
+
+    cpu_engine.set_model(oracle_mod.ModelSpec(500), 1)
+    data = synthetic_data(cpu_engine)
+    lo, hi = np.array([0.0, 0.005, 0.005]), np.array([1e4, 0.02, 0.03])
+    q0 = np.array([[1000.0, 0.011, 0.014], [1500.0, 0.008, 0.02], [400.0, 0.016, 0.009]])
+    V = {}
+    for fd in (1e-6, 1e-4):
+        cpu_engine.mcmc_init(q0, data, lo, hi, seed=1, fd_rel_step=fd)
+        _, ssq, std2, V[fd] = [np.array(x) for x in cpu_engine.get_state()]
+    # the regularised form does not live off the small step (entries compared on the scale sqrt(V_pp V_rr): the correlations
+    # with b are ~1e-5, i.e. zero, and have no relative accuracy to speak of)
+    sd = np.sqrt(np.diagonal(V[1e-4], axis1=1, axis2=2))
+    assert (np.abs(V[1e-6] - V[1e-4]) <= 1e-4 * sd[:, :, None] * sd[:, None, :]).all()
+    W = hi - lo
+    for c in range(3):
+        # the formula, from sensitivities formed here (perturbed value in the denominator, MCMC.py:251, 264)
+        _, acc0 = cpu_engine.forward([q0[c, 0]], a=[q0[c, 1]], b=[q0[c, 2]])
+        X = []
+        for p in range(3):
+            qp = q0[c].copy()
+            qp[p] *= 1 + 1e-4
+            _, ap = cpu_engine.forward([qp[0]], a=[qp[1]], b=[qp[2]])
+            X.append((ap[:, 0] - acc0[:, 0]) / (qp[p] * 1e-4))
+        X = np.array(X).T
+        M = (W[:, None] * (X.T @ X) * W[None, :]) / std2[c] + 12.0 * np.eye(3)
+        sd = np.sqrt(np.diag(V[1e-4][c]))
+        assert (np.abs(V[1e-4][c] - W[:, None] * np.linalg.inv(M) * W[None, :]) <= 1e-7 * np.outer(sd, sd)).all()
+        corr = V[1e-4][c] / np.outer(sd, sd)
+        assert corr[0, 1] < -0.98                                  # the ridge Dc * a = const
+        eig = np.linalg.eigvalsh(V[1e-4][c] / np.outer(W, W))
+        assert eig.max() <= 1 / 12 + 1e-12 and eig.min() > 0      # never wider than the prior; positive definite
+        assert eig[0] < 1e-3 and eig[1] > 0.9 / 12                 # one direction the data pin down, two the prior does
+        assert abs(sd[2] / (W[2] / np.sqrt(12)) - 1) < 1e-3       # b: the width of its box
+
+
+def test_three_parameter_chains_recover_what_the_data_identify(cpu_engine, oracle_mod):
+    """Chains from that initial covariance, started away from the truth, with corrected adaptive Metropolis: the identified
+    combination Dc * a comes back to the truth's 11.0, b fills its box, and the adapted proposal is accepted at a rate in
+    random-walk Metropolis's useful range (neither timid nor wild)."""
+    from conftest import synthetic_data
+
+    cpu_engine.set_model(oracle_mod.ModelSpec(500), 1)
+    data = synthetic_data(cpu_engine)
+    lo, hi = [0.0, 0.005, 0.005], [1e4, 0.02, 0.03]
+    acc = {}
+    for mode in ("none", "am"):
+        cpu_engine.mcmc_init(np.tile([1600.0, 0.008, 0.022], (128, 1)), data, lo, hi, seed=3, fd_rel_step=1e-4, adapt_mode=mode, adapt_interval=20)
+        tq, _, ta = cpu_engine.mcmc_run(500)
+        acc[mode] = ta[250:].mean()
+        prod = tq[250:, :, 0] * tq[250:, :, 1]
+        assert abs(prod.mean() - 11.0) < 1.0 and 0.2 < prod.std() < 1.2, (mode, prod.mean(), prod.std())
+        assert abs(tq[250:, :, 2].mean() - 0.0175) < 0.003 and tq[250:, :, 2].std() > 0.005
+        assert cpu_engine.counters()["nonfinite"] == 0
+    assert 0.1 < acc["none"] < 0.5 and 0.12 < acc["am"] < 0.5, acc
+
+
 def test_dict_prior_adaptation_is_numpys_covariance_to_the_bit_that_matters(pkg, cpu_engine):
     import likelihood_operator as lo
 

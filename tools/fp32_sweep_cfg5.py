@@ -55,12 +55,11 @@ def sweep(iters=400, chains=CHAINS, nsteps=NSTEPS, seed=9):
                   "rel_max": float(rel.max()), "rel_p999": float(np.quantile(rel, 0.999)), "rel_median": float(np.median(rel))}
     res = {}
     q0 = torch.tensor([1000.0, 0.011, 0.014], dtype=torch.float64, device="cuda").repeat(chains, 1)
-    V0 = torch.diag(torch.tensor([20.0 ** 2, 1e-4 ** 2, 1e-4 ** 2], dtype=torch.float64, device="cuda")).repeat(chains, 1, 1)
     for p in ("float64", "float32"):
         with pkg.Engine(mem="device") as e:
             e.set_model(m[p], 1)
-            e.mcmc_init(q0, d_dev, LO, HI, seed=seed, adapt_mode="am", adapt_interval=10)
-            e.set_state(V=V0)   # (X^T X)^-1 is near-singular for (Dc, a, b): explicit start covariance
+            # the init kernel's own proposal covariance (prior-regularised, float64 sensitivities in both precisions): nothing hand-set
+            e.mcmc_init(q0, d_dev, LO, HI, seed=seed, prior_len=3, adapt_mode="am", adapt_interval=20, fd_rel_step=1e-4)
             e.mcmc_run(2, traces=False)
             e.sync()
             t0 = time.perf_counter()
