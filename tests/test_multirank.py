@@ -70,3 +70,18 @@ def test_plain_c_caller_drives_two_ctxs_on_the_gpu(fake_rccl, pkg, tmp_path):
     out = subprocess.run([str(exe)], capture_output=True, text=True, check=True,
                          env=dict(os.environ, RSF_RCCL_LIB=fake_rccl, FAKE_RCCL_HIP="1")).stdout.split("\n")
     assert out[3].startswith("backend hip-gfx950") and "pool ok" in out and "pool2 ok" in out, out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("label,chains,nsteps,params,iters,sample", [("configs[3]", 2097152, 500, 1, 3, 32768), ("configs[4]", 1048576, 4000, 3, 2, 8192)])
+def test_full_chain_counts_of_the_eight_gpu_configs_on_one_gpu(fake_rccl, label, chains, nsteps, params, iters, sample):
+    """BASELINE configs[3] (2 097 152 chains, nsteps 500) and configs[4] (1 048 576 chains, joint (Dc, a, b), nsteps 4000) at
+    their FULL chain counts: eight ctxs with the eight chain_offsets a node's ranks would have (262 144 / 131 072 chains
+    each, device buffers), pooled through rsf_comm_init + rsf_pool_allgather (thread per rank, twice) and rsf_comm_init_all
+    + the grouped calls (one thread) with the RCCL stand-in, every receive buffer bit-equal to ONE ctx holding all the
+    chains; and 8 x `sample` of those chains, taken from every shard, against the CPU checker under the same global ids.
+    Both configurations fit one GPU's HBM many times over; what the 8-GPU node adds is RCCL's transport and seven more
+    devices, not a different computation."""
+    res = run_driver(fake_rccl, "--lib", "hip", "--mem", "device", "--params", str(params), "--chains", str(chains), "--nsteps", str(nsteps),
+                     "--iters", str(iters), "--worlds", "8", "--oracle-sample", str(sample), hip=True)
+    assert res["checks"] > 150, res
