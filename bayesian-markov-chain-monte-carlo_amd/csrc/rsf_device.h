@@ -205,6 +205,17 @@ __device__ __forceinline__ bool guard_ok(const Guard &g) {  // NaN passes throug
          (g.dlt < (T == TIGHT ? hi_pow2(-9) : (T == NARROW ? hi_pow2(-7) : hi_pow2(-5)))) && (T != TIGHT || g.dlt_h < hi_pow2(-10));
 }
 
+// Would the increments this trip measured also have fitted the next TIGHTER tier's guard, with a quarter to spare?  (The
+// evidence a wave demotes itself on, struct Wave.)  Thresholds: 3/4 of tier T-1's bounds — 0.75 * 2^e has the high word
+// of 1.5 * 2^(e-1).
+constexpr float hi_pow2_34(int e) { return __builtin_bit_cast(float, ((1023 + e - 1) << 20) | 0x80000); }
+template <int T>
+__device__ __forceinline__ bool calm_enough(const Guard &g) {
+  static_assert(T == NARROW || T == WIDE, "TIGHT has no tighter tier");
+  return T == WIDE ? (g.rho < hi_pow2_34(-14) && g.dlt < hi_pow2_34(-7))
+                   : (g.rho < hi_pow2_34(-20) && g.dlt < hi_pow2_34(-10));  // (TIGHT's half-step bound 2^-10 for every stage: stricter, simpler)
+}
+
 // ---------------------------------------------------------------------------------------------
 // One classical RK4 step of size h; vl0/vlm/vl1 = V_l at t, t+h/2, t+h.
 //
@@ -414,10 +425,13 @@ __device__ __forceinline__ void emit_sample(double vnow, Emit &em, double obs, c
 // dv[j] = the weighted V-derivative sum of step j.  Returns whether this lane left the tier's guard region — its
 // values are then not to be used: the caller restores the state it saved and takes trip_cold.
 template <bool DAMP, int T, int NU>
-__device__ __forceinline__ bool trip_fast(const double *v, const Lane &L, const Consts &K, State &s, double (&dv)[NU]) {
+__device__ __forceinline__ bool trip_fast(const double *v, const Lane &L, const Consts &K, State &s, double (&dv)[NU], bool *calm = nullptr) {
   Guard g = {0, 0, 0};
 #pragma unroll
   for (int j = 0; j < NU; ++j) dv[j] = rk4_tight<DAMP, T>(s, v[2 * j], v[2 * j + 1], v[2 * j + 2], L, K, g);
+  if constexpr (T != TIGHT) {
+    if (calm) *calm = calm_enough<T>(g);
+  }
   return !guard_ok<T>(g);
 }
 
@@ -453,14 +467,22 @@ __device__ __forceinline__ void trip_cold(const double *v, const Lane &L, const 
 //          whose WIDE guard trips, left again after kFullRetry steps to try WIDE once more (`stiff` lanes, whose a-priori
 //          bound is beyond 2^-3, stay).  Until round 4 a tripped WIDE trip was redone cold and the next trip tried the
 //          fast step again: a wave with one stiff lane paid fast + cold on every trip.
+// calm     demotion on evidence.  The a-priori classes are BOUNDS (|V_l - v| <~ 1.2 V_ref), and the loading oscillation that
+//          drives the increments decays like exp(-t/20): a lane that needs WIDE for its first forty steps is fine in NARROW for
+//          the other four hundred.  Every trip measures its largest increments anyway (Guard); when, for kCalmSteps steps
+//          in a row (two periods of the oscillation at h = 0.1), every alive lane's would also have fitted the next tighter
+//          tier's guard with a quarter to spare, the wave's alive lanes move one tier tighter.  If that turns out wrong the
+//          ordinary escalation takes the lane back (one cold trip) — rare, because the evidence is the increments themselves.
 // ---------------------------------------------------------------------------------------------
 constexpr int kFullRetry = 32;
+constexpr int kCalmSteps = 16;  // steps of evidence before a wave demotes itself one tier (>= two loading periods at h = 0.1)
 struct Wave {
   unsigned long long alive;
   unsigned long long need[3];
   unsigned long long stiff;
   int next_resync;   // chunk-local step at which (w, Rh) are next re-evaluated in full (kResync)
   int full_run;      // steps since the FULL tier was (re-)entered
+  int calm;          // consecutive steps in which every alive lane's increments would have fitted the next tighter tier
   // statistics of this solve (rsf_mcmc_counters): wave-steps per tier, wave-steps of fast trips thrown away by a tripped
   // guard, and the sum over steps of the number of alive lanes (lane utilisation = lane_steps / (64 * all steps))
   uint32_t steps[4], redone, lane_steps;
@@ -478,6 +500,7 @@ __device__ __forceinline__ void wave_begin(Wave &W, bool active, const Lane &L, 
   W.need[2] = W.stiff = ballot(active && !(dk < 0x1.0p-3));
   W.next_resync = kResync;
   W.full_run = 0;
+  W.calm = 0;
 }
 
 __device__ __forceinline__ int wave_tier(const Wave &W) {
@@ -536,10 +559,14 @@ __device__ __forceinline__ int integrate_multi(const double *lds, const double *
       W.next_resync = (r & ~(kResync - 1)) + kResync;
     }
     const State save = s;
-    const bool bad = trip_fast<DAMP, T, NU>(v, L, K, s, dv);
+    bool calm = false;
+    const bool bad = trip_fast<DAMP, T, NU>(v, L, K, s, dv, &calm);
     const unsigned long long badmask = ballot(bad) & W.alive;  // wave-uniform, straight from the compares
     W.steps[T] += NU;
     W.lane_steps += NU * (uint32_t)__builtin_popcountll(W.alive);
+    if constexpr (T != TIGHT) {  // evidence for one tier tighter: every alive lane calm in this trip (struct Wave)
+      W.calm = (ballot(!calm) & W.alive) == 0 ? W.calm + NU : 0;
+    }
     if (__builtin_expect(badmask != 0, 0)) {  // scalar branch: the hot path carries no exec-mask bookkeeping
       if (lane_in(badmask)) {
         s = save;
@@ -548,9 +575,16 @@ __device__ __forceinline__ int integrate_multi(const double *lds, const double *
       W.need[T] |= badmask;
       W.redone += NU;
       W.full_run = 0;
+      W.calm = 0;
     }
     emit_trip<WANT_SSQ, WANT_ACC, S1, NU>(dv, obs, ld, r, s, em, L, K, k0, ssq, active, acc_out, stride);
     W.alive &= ~deadmask;
+    if constexpr (T != TIGHT) {
+      if (W.calm >= kCalmSteps && badmask == 0) {  // demote: constant index (a run-time one would put the Wave in scratch memory)
+        W.need[T - 1] &= ~W.alive | W.stiff;
+        W.calm = 0;
+      }
+    }
     if (badmask != 0 || W.alive == 0 || (T != TIGHT && (W.need[T - 1] & W.alive) == 0)) return r + NU;
   }
   return r;

@@ -6,6 +6,7 @@
 #include <rccl/rccl.h>  // types and prototypes only: the library is bound with dlopen (see struct Rccl)
 #include <dlfcn.h>
 
+#include <climits>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -402,6 +403,7 @@ int run_mcmc(rsf_ctx *c, int64_t n_iters, const double *z, const double *u, cons
   if (!c->have_chains) return fail(RSF_ERR_STATE, "rsf_mcmc_run: call rsf_mcmc_init first");
   if (c->external_chains && !ssq_new)
     return fail(RSF_ERR_STATE, "chains made by rsf_mcmc_init_state have no observation: advance them with rsf_mcmc_replay_ssq");
+  if (n_iters > INT32_MAX) return fail(RSF_ERR_INVALID, "at most 2^31 - 1 iterations per call (every lane counts its own)");
   if (n_iters == 0) return RSF_OK;
   DeviceGuard guard(c->device);
   if (!guard.ok) return fail(RSF_ERR_DEVICE, "rsf_mcmc_run: cannot select device %d", c->device);
