@@ -449,6 +449,19 @@ __device__ __forceinline__ void trip_cold(const double *v, const Lane &L, const 
   eval_full_t<T>(s, L, K);
 }
 
+// the same for a caller that holds the PLAIN state between trips — (ms, x) with rx = 1 / x, as the init kernels do: cold steps
+// straight from (ms, x), then (w, 1/x) re-evaluated at the trip's end point
+template <bool DAMP, int NU>
+__device__ __forceinline__ void trip_cold_plain(const double *v, const Lane &L, const Consts &K, State &s, double (&dv)[NU]) {
+#pragma unroll 1
+  for (int j = 0; j < NU; ++j) {  // one copy of the cold step; its result goes to dv[j] by selects, so that dv stays in registers
+    const double r = rk4_cold<DAMP>(s, v[2 * j], v[2 * j + 1], v[2 * j + 2], L, K);
+#pragma unroll
+    for (int m = 0; m < NU; ++m) dv[m] = m == j ? r : dv[m];
+  }
+  eval_full(s.ms, s.x, L, K, s.w, s.rx);
+}
+
 // ---------------------------------------------------------------------------------------------
 // Wave-level control of one forward solve.  Every member is wave-uniform (ballots, step counts), i.e. lives in SGPRs.
 //

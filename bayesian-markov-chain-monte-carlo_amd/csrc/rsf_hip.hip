@@ -773,21 +773,23 @@ int rsf_mcmc_init(rsf_ctx *c, const rsf_mcmc_config *cfg, const double *q0, cons
   Consts K = make_consts(c, (const double *)c->data.p);
   K.group_chains = c->group_chains;
   const dim3 grid(grid_for(c, C)), block(c->block);
+  // the init kernels run one lane per TRAJECTORY: 1 + d adjacent lanes per chain (rsf_kernels.h, InitGroup)
+  const dim3 igrid((unsigned)((C * (d + 1) + c->block - 1) / c->block));
   const bool damp = c->m.flags & RSF_FLAG_RADIATION_DAMPING;
   if (c->m.flags & RSF_FLAG_DOP853) {
     if (d == 1) {
-      if (damp) hipLaunchKernelGGL((init_dp_kernel<1, true>), grid, block, c->lds_bytes, c->stream, K, A);
-      else hipLaunchKernelGGL((init_dp_kernel<1, false>), grid, block, c->lds_bytes, c->stream, K, A);
+      if (damp) hipLaunchKernelGGL((init_dp_kernel<1, true>), igrid, block, c->lds_bytes, c->stream, K, A);
+      else hipLaunchKernelGGL((init_dp_kernel<1, false>), igrid, block, c->lds_bytes, c->stream, K, A);
     } else {
-      if (damp) hipLaunchKernelGGL((init_dp_kernel<3, true>), grid, block, c->lds_bytes, c->stream, K, A);
-      else hipLaunchKernelGGL((init_dp_kernel<3, false>), grid, block, c->lds_bytes, c->stream, K, A);
+      if (damp) hipLaunchKernelGGL((init_dp_kernel<3, true>), igrid, block, c->lds_bytes, c->stream, K, A);
+      else hipLaunchKernelGGL((init_dp_kernel<3, false>), igrid, block, c->lds_bytes, c->stream, K, A);
     }
   } else if (d == 1) {
-    if (damp) hipLaunchKernelGGL((init_kernel<1, true>), grid, block, c->lds_bytes, c->stream, K, A);
-    else hipLaunchKernelGGL((init_kernel<1, false>), grid, block, c->lds_bytes, c->stream, K, A);
+    if (damp) hipLaunchKernelGGL((init_kernel<1, true>), igrid, block, c->lds_bytes, c->stream, K, A);
+    else hipLaunchKernelGGL((init_kernel<1, false>), igrid, block, c->lds_bytes, c->stream, K, A);
   } else {
-    if (damp) hipLaunchKernelGGL((init_kernel<3, true>), grid, block, c->lds_bytes, c->stream, K, A);
-    else hipLaunchKernelGGL((init_kernel<3, false>), grid, block, c->lds_bytes, c->stream, K, A);
+    if (damp) hipLaunchKernelGGL((init_kernel<3, true>), igrid, block, c->lds_bytes, c->stream, K, A);
+    else hipLaunchKernelGGL((init_kernel<3, false>), igrid, block, c->lds_bytes, c->stream, K, A);
   }
   if (c->m.flags & RSF_FLAG_FP32_SOLVE) {
     if (d == 1) {

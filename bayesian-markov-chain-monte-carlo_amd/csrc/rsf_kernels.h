@@ -18,6 +18,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "../../include/rsf_abi.h"
 #include "rsf_device.h"
 #include "rsf_device_dop853.h"
@@ -121,228 +123,178 @@ __device__ __forceinline__ void initial_covariance(const double *xtx, double std
   }
 }
 
-// One trip of NU steps for the unperturbed trajectory and its D perturbed companions, each with its own lane constants
-template <int D, bool DAMP, int T, int NU>
-__device__ __forceinline__ bool lockstep_trip(const double *v, const rsf::Lane (&L)[D + 1], const Consts &K, rsf::State (&st)[D + 1],
-                                              double (&dv)[D + 1][NU]) {
-  bool bad = false;
-#pragma unroll
-  for (int t = 0; t <= D; ++t) {
-    rsf::Lane Lt = L[t];
-    rsf::set_tier<T>(Lt);
-    rsf::tier_enter<T>(st[t], Lt);  // (the TIGHT tier's representation of 1/x, for this trip only)
-    bad |= rsf::trip_fast<DAMP, T, NU>(v, Lt, K, st[t], dv[t]);
-    rsf::tier_leave<T>(st[t], Lt);
-  }
-  return bad;
-}
+// compute_initial_covariance + the initial SSq (MCMC.py:244-266, 468): ONE LANE PER TRAJECTORY.  A chain owns a group of
+// G = D + 1 adjacent lanes (a pair for one parameter, a quad for three): lane 0 of the group integrates the chain's start
+// point, lane p + 1 the point with parameter p moved by the forward-difference step (MCMC.py:251) — each with the sampler's
+// own straight-line tier code and nothing but the forward kernel's registers.  Where an output sample completes, the
+// group's lanes exchange their acceleration samples by lane shuffles: every lane forms its sensitivity against lane 0's
+// sample (perturbed value in the denominator, MCMC.py:264), lane 0 collects them and accumulates the residual and X^T X,
+// sample by sample, without storing trajectories.  (Until round 4 ONE lane carried all 1 + D trajectories in lockstep: four
+// sets of lane constants and states, 256 VGPRs + 42-120 AGPRs of spills, one wave per SIMD.)
+// The acceleration sample is cv * (sum of the interval's weighted V-derivative sums), like the sampler's (rsf::emit_incr):
+// the initial SSq is the value the sampler computes for the same point to rounding, and the difference of two trajectories'
+// samples — which a relative step of 1e-6 amplifies a million-fold — does not go through two velocities near V_ref.
+template <int D>
+struct InitGroup {
+  static constexpr int G = D + 1;  // lanes per chain: 2 or 4, a power of two, so a group never straddles a wave
+  const unsigned t = threadIdx.x;
+  const int tr = (int)(t & (G - 1));                                              // which trajectory of its chain this lane integrates
+  const int64_t chain = (int64_t)blockIdx.x * (blockDim.x / G) + (t / G);
+  const int lane0 = (int)((t & 63) & ~(unsigned)(G - 1));                         // the group's first lane within the wave
+  double xtx[D * D], ssq = 0.0;
 
-// Per chain: the unperturbed solve and one perturbed solve per parameter advance in lockstep, trip by trip, through the
-// same straight-line tier code as the sampler's hot loop (rsf::trip_fast; a tripped guard redoes the trip for all of them
-// with full evaluations and moves on to the next wider tier), so the sensitivity products X^T X accumulate sample by
-// sample without storing trajectories.  The acceleration sample is cv * (sum of the interval's weighted V-derivative
-// sums), like the sampler's (rsf::emit_incr): the initial SSq is the value the sampler computes
-// for the same point to rounding, and the difference of two trajectories' samples — the forward-difference
-// sensitivity, which a relative step of 1e-6 amplifies a million-fold — does not go through two velocities near V_ref.
+  __device__ __forceinline__ InitGroup() {
+#pragma unroll
+    for (int e = 0; e < D * D; ++e) xtx[e] = 0.0;
+  }
+  // the observation series of the workgroup's chain group (all of a workgroup's chains belong to one)
+  __device__ __forceinline__ void select_group(Consts &K) const {
+    if (K.group_chains > 0) K.data += (((int64_t)blockIdx.x * (blockDim.x / G)) / K.group_chains) * K.nout;
+  }
+  // this lane's parameter vector (Dc, a, b) and, for a perturbed trajectory, 1 / (perturbed value * step)
+  __device__ __forceinline__ void parameters(const Consts &K, const InitArgs &A, bool active, double (&pq)[3], double &inv_den) const {
+    pq[0] = 1000.0; pq[1] = K.a_def; pq[2] = K.b_def;
+    if (active) {
+      pq[0] = A.q0[chain];
+      if (D == 3) { pq[1] = A.q0[A.C + chain]; pq[2] = A.q0[2 * A.C + chain]; }
+    }
+    inv_den = 0.0;
+#pragma unroll
+    for (int p = 0; p < D; ++p)
+      if (tr == p + 1) {
+        pq[p] = pq[p] * (1 + A.fd);
+        inv_den = 1.0 / (pq[p] * A.fd);  // perturbed value in the denominator, MCMC.py:264
+      }
+  }
+  // an output sample is complete: ak = this lane's acceleration sample, obs the observation (every lane of the group calls)
+  __device__ __forceinline__ void sample(double ak, double obs, double inv_den) {
+    const double ak0 = __shfl(ak, lane0, 64);
+    const double x = (ak - ak0) * inv_den;  // lane p + 1: the sensitivity to parameter p; lane 0: 0
+    double xs[D];
+#pragma unroll
+    for (int p = 0; p < D; ++p) xs[p] = __shfl(x, lane0 + p + 1, 64);
+    const double r = ak - obs;  // meaningful in lane 0 (the others accumulate values nobody reads)
+    ssq = __builtin_fma(r, r, ssq);
+#pragma unroll
+    for (int p = 0; p < D; ++p)
+#pragma unroll
+      for (int r2 = 0; r2 < D; ++r2) xtx[p * D + r2] = __builtin_fma(xs[p], xs[r2], xtx[p * D + r2]);
+  }
+  __device__ __forceinline__ void finish(const InitArgs &A, bool active) const {
+    if (active && tr == 0) {
+      const double std2 = ssq * A.inv_dof;
+      double V[D * D];
+      initial_covariance<D>(xtx, std2, A.width, V);
+#pragma unroll
+      for (int e = 0; e < D * D; ++e) A.V[e * A.C + chain] = V[e];  // MCMC.py:266
+      A.std2[chain] = std2;
+      A.ssq[chain] = ssq;
+    }
+  }
+};
+
 template <int D, bool DAMP>
-__global__ void __launch_bounds__(kMaxBlock) init_kernel(Consts K, InitArgs A) {
+__global__ void __launch_bounds__(kMaxBlock, kMinBlocks) init_kernel(Consts K, InitArgs A) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
-  constexpr int NU = 4;
+  constexpr int NU = 8;
   static_assert(rsf::kResync % NU == 0, "the resync test looks at the first step of a trip");
-  rsf::select_group(K);
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const bool active = i < A.C;
-  double p0[3] = {1.0, K.a_def, K.b_def};
-  if (active) {
-    p0[0] = A.q0[i];
-    if (D == 3) { p0[1] = A.q0[A.C + i]; p0[2] = A.q0[2 * A.C + i]; }
-  }
-  rsf::Lane L[D + 1];
-  rsf::State st[D + 1];
-  double inv_den[D], dsum[D + 1];
-  L[0] = rsf::make_lane(p0[0], p0[1], p0[2], K);
-  st[0] = rsf::initial_state(p0[0], L[0], K);
-  dsum[0] = 0.0;
-#pragma unroll
-  for (int p = 0; p < D; ++p) {
-    double pq[3] = {p0[0], p0[1], p0[2]};
-    pq[p] = pq[p] * (1 + A.fd);
-    inv_den[p] = 1.0 / (pq[p] * A.fd);  // perturbed value in the denominator, MCMC.py:264
-    L[p + 1] = rsf::make_lane(pq[0], pq[1], pq[2], K);
-    st[p + 1] = rsf::initial_state(pq[0], L[p + 1], K);
-    dsum[p + 1] = 0.0;
-  }
-  double xtx[D * D];
-#pragma unroll
-  for (int e = 0; e < D * D; ++e) xtx[e] = 0.0;
-  double ssq = 0.0;
-  if (active) { const double d0 = K.data[0]; ssq = d0 * d0; }
+  InitGroup<D> grp;
+  grp.select_group(K);
+  const bool active = grp.chain < A.C;
+  double pq[3], inv_den;
+  grp.parameters(K, A, active, pq, inv_den);
+  const rsf::Lane L = rsf::make_lane(pq[0], pq[1], pq[2], K);
+  rsf::State st = rsf::initial_state(pq[0], L, K);
+  double dsum = 0.0;
+  if (active) { const double d0 = K.data[0]; grp.ssq = d0 * d0; }
   const double *ld = lds + rsf::lds_data_offset(K);
   int phase = 0;  // RK4 steps since the last output sample (wave-uniform)
   for (int k0 = 1; k0 < K.nout; k0 += K.kc) {
     const int kn = min(K.kc, K.nout - k0);
     rsf::stage_chunk(lds, K, k0, kn);
-    if (!active) continue;
     const int nsteps = K.S * kn;
     int ko = 0;
-    // an output sample is complete: residual, and the sensitivities' outer product (MCMC.py:264-265)
     auto emit = [&]() {
-      double ak[D + 1];
-#pragma unroll
-      for (int t = 0; t <= D; ++t) ak[t] = dsum[t] * L[t].cv;
-      const double r = __builtin_fma(dsum[0], L[0].cv, -ld[ko]);
-      ssq = __builtin_fma(r, r, ssq);
-      double x[D];
-#pragma unroll
-      for (int p = 0; p < D; ++p) x[p] = (ak[p + 1] - ak[0]) * inv_den[p];
-#pragma unroll
-      for (int p = 0; p < D; ++p)
-#pragma unroll
-        for (int r2 = 0; r2 < D; ++r2) xtx[p * D + r2] = __builtin_fma(x[p], x[r2], xtx[p * D + r2]);
-#pragma unroll
-      for (int t = 0; t <= D; ++t) dsum[t] = 0.0;
+      grp.sample(dsum * L.cv, ld[ko], inv_den);
+      dsum = 0.0;
       ++ko;
     };
-    int tier = rsf::start_tier(L[0], K);  // wave-uniform; the companions differ from L[0] by 1e-6
+    // (every lane of the wave integrates — lanes past the last chain carry a harmless Dc = 1000 — so that the shuffles
+    // and the wave-uniform tier decisions see whole waves)
+    int tier = rsf::start_tier(L, K);
     int r = 0;
-    for (; r + NU <= nsteps; r += NU) {
+    auto trip = [&](auto tier_tag, auto nu_tag) {  // one trip of tier T, NUT steps; a tripped guard: that lane redoes it in full
+      constexpr int T = decltype(tier_tag)::value, NUT = decltype(nu_tag)::value;
       const double *v = lds + 2 * r;
-      if ((r & (rsf::kResync - 1)) == 0) {
-#pragma unroll
-        for (int t = 0; t <= D; ++t) rsf::eval_full(st[t].ms, st[t].x, L[t], K, st[t].w, st[t].rx);
-      }
-      rsf::State save[D + 1];
-#pragma unroll
-      for (int t = 0; t <= D; ++t) save[t] = st[t];
-      double dv[D + 1][NU];
-      bool bad;
-      if (tier == rsf::TIGHT) bad = lockstep_trip<D, DAMP, rsf::TIGHT, NU>(v, L, K, st, dv);
-      else if (tier == rsf::NARROW) bad = lockstep_trip<D, DAMP, rsf::NARROW, NU>(v, L, K, st, dv);
-      else bad = lockstep_trip<D, DAMP, rsf::WIDE, NU>(v, L, K, st, dv);
-      if (__builtin_expect(__builtin_amdgcn_ballot_w64(bad) != 0, 0)) {
-        if (bad) {
-#pragma unroll
-          for (int t = 0; t <= D; ++t) {
-            st[t] = save[t];
-            rsf::trip_cold<DAMP, rsf::WIDE, NU>(v, L[t], K, st[t], dv[t]);
-          }
+      rsf::Lane Lt = L;
+      rsf::set_tier<T>(Lt);
+      const rsf::State save = st;
+      double dv[NUT];
+      rsf::tier_enter<T>(st, Lt);
+      const bool bad = rsf::trip_fast<DAMP, T, NUT>(v, Lt, K, st, dv);
+      rsf::tier_leave<T>(st, Lt);
+      const bool any_bad = rsf::ballot(bad) != 0;
+      if (__builtin_expect(any_bad, 0)) {
+        if (bad) {  // back to the trip's start (the plain state: saved before tier_enter) and through it with full evaluations
+          st = save;
+          rsf::trip_cold_plain<DAMP, NUT>(v, L, K, st, dv);
         }
-        if (tier < rsf::WIDE) ++tier;
       }
 #pragma unroll
-      for (int j = 0; j < NU; ++j) {
-#pragma unroll
-        for (int t = 0; t <= D; ++t) dsum[t] += dv[t][j];
+      for (int j = 0; j < NUT; ++j) {
+        dsum += dv[j];
         if (++phase == K.S) { phase = 0; emit(); }
       }
+      return any_bad;
+    };
+    for (; r + NU <= nsteps; r += NU) {
+      if ((r & (rsf::kResync - 1)) == 0) rsf::eval_full(st.ms, st.x, L, K, st.w, st.rx);
+      bool any_bad;
+      if (tier == rsf::TIGHT) any_bad = trip(std::integral_constant<int, rsf::TIGHT>{}, std::integral_constant<int, NU>{});
+      else if (tier == rsf::NARROW) any_bad = trip(std::integral_constant<int, rsf::NARROW>{}, std::integral_constant<int, NU>{});
+      else any_bad = trip(std::integral_constant<int, rsf::WIDE>{}, std::integral_constant<int, NU>{});
+      if (any_bad && tier < rsf::WIDE) ++tier;
     }
     for (; r < nsteps; ++r) {  // fewer than NU steps left in the chunk: one at a time
-      const double *v = lds + 2 * r;
-      bool bad = false;
-      rsf::State save[D + 1];
-      double dv[D + 1][1];
-#pragma unroll
-      for (int t = 0; t <= D; ++t) {
-        if ((r & (rsf::kResync - 1)) == 0) rsf::eval_full(st[t].ms, st[t].x, L[t], K, st[t].w, st[t].rx);
-        save[t] = st[t];
-      }
-      bad = lockstep_trip<D, DAMP, rsf::WIDE, 1>(v, L, K, st, dv);
-      if (__builtin_expect(__builtin_amdgcn_ballot_w64(bad) != 0, 0)) {
-        if (bad) {
-#pragma unroll
-          for (int t = 0; t <= D; ++t) {
-            st[t] = save[t];
-            rsf::trip_cold<DAMP, rsf::WIDE, 1>(v, L[t], K, st[t], dv[t]);
-          }
-        }
-      }
-#pragma unroll
-      for (int t = 0; t <= D; ++t) dsum[t] += dv[t][0];
-      if (++phase == K.S) { phase = 0; emit(); }
+      if ((r & (rsf::kResync - 1)) == 0) rsf::eval_full(st.ms, st.x, L, K, st.w, st.rx);
+      trip(std::integral_constant<int, rsf::WIDE>{}, std::integral_constant<int, 1>{});
     }
   }
-  if (active) {
-    const double std2 = ssq * A.inv_dof;
-    double V[D * D];
-    initial_covariance<D>(xtx, std2, A.width, V);
-#pragma unroll
-    for (int e = 0; e < D * D; ++e) A.V[e * A.C + i] = V[e];  // MCMC.py:266
-    A.std2[i] = std2;
-    A.ssq[i] = ssq;
-  }
+  grp.finish(A, active);
 }
 
-// compute_initial_covariance + initial SSq in the reference's DOP853 scheme: the unperturbed and the perturbed
-// trajectories take their dop853 calls interval by interval in one lane (each with its own carried step size).
+// compute_initial_covariance + initial SSq in the reference's DOP853 scheme, one lane per trajectory like init_kernel: every
+// lane takes its own dop853 calls interval by interval (its own carried step size); the group's lanes meet at every
+// output sample.
 template <int D, bool DAMP>
-__global__ void __launch_bounds__(kMaxBlock) init_dp_kernel(Consts K, InitArgs A) {
+__global__ void __launch_bounds__(kMaxBlock, kMinBlocks) init_dp_kernel(Consts K, InitArgs A) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
-  rsf::select_group(K);
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const bool active = i < A.C;
-  double p0[3] = {1.0, K.a_def, K.b_def};
-  if (active) {
-    p0[0] = A.q0[i];
-    if (D == 3) { p0[1] = A.q0[A.C + i]; p0[2] = A.q0[2 * A.C + i]; }
-  }
-  rsf::dp::LaneD L[D + 1];
-  rsf::dp::Carry cw[D + 1];
-  double y[D + 1][3], x[D + 1], vprev[D + 1], inv_den[D];
-  bool failed[D + 1];
-#pragma unroll
-  for (int t = 0; t <= D; ++t) {
-    double pq[3] = {p0[0], p0[1], p0[2]};
-    if (t > 0) {
-      pq[t - 1] = pq[t - 1] * (1 + A.fd);
-      inv_den[t - 1] = 1.0 / (pq[t - 1] * A.fd);  // perturbed value in the denominator, MCMC.py:264
-    }
-    L[t] = rsf::dp::make_lane_dp(pq[0], pq[1], pq[2]);
-    cw[t] = rsf::dp::fresh_carry();
-    y[t][0] = K.mu0; y[t][1] = pq[0] / K.V_ref; y[t][2] = K.V_ref;
-    x[t] = K.t0; vprev[t] = K.V_ref; failed[t] = false;
-  }
-  double xtx[D * D];
-#pragma unroll
-  for (int e = 0; e < D * D; ++e) xtx[e] = 0.0;
-  double ssq = 0.0;
-  if (active) { const double d0 = K.data[0]; ssq = d0 * d0; }
+  InitGroup<D> grp;
+  grp.select_group(K);
+  const bool active = grp.chain < A.C;
+  double pq[3], inv_den;
+  grp.parameters(K, A, active, pq, inv_den);
+  const rsf::dp::LaneD L = rsf::dp::make_lane_dp(pq[0], pq[1], pq[2]);
+  rsf::dp::Carry cw = rsf::dp::fresh_carry();
+  double y[3] = {K.mu0, pq[0] / K.V_ref, K.V_ref}, x = K.t0, vprev = K.V_ref;
+  bool failed = false;
+  if (active) { const double d0 = K.data[0]; grp.ssq = d0 * d0; }
   const double *ld = lds + rsf::dp::lds_data_offset_dp(K);
   const double delta_t = K.dt;
   for (int k0 = 1; k0 < K.nout; k0 += K.kc) {
     const int kn = min(K.kc, K.nout - k0);
     rsf::dp::stage_chunk_dp(lds, K, k0, kn);
-    if (!active) continue;
     for (int kk = 0; kk < kn; ++kk) {
-      double ak[D + 1];
-#pragma unroll
-      for (int t = 0; t <= D; ++t) {
-        ak[t] = 0.0;
-        if (!failed[t]) {
-          failed[t] = !rsf::dp::call<DAMP>(K, L[t], lds + rsf::dp::kTab * kk, x[t], x[t] + delta_t, y[t], cw[t], true);
-          ak[t] = (y[t][2] - vprev[t]) * K.inv_dt;
-          vprev[t] = y[t][2];
-        }
+      double ak = 0.0;  // a trajectory whose integrator failed leaves zeros, like the reference (RateStateModel.py:361-366, 381)
+      if (!failed) {
+        failed = !rsf::dp::call<DAMP>(K, L, lds + rsf::dp::kTab * kk, x, x + delta_t, y, cw, true);
+        ak = (y[2] - vprev) * K.inv_dt;
+        vprev = y[2];
       }
-      const double r = ak[0] - ld[kk];
-      ssq += r * r;
-      double xs[D];
-#pragma unroll
-      for (int p = 0; p < D; ++p) xs[p] = (ak[p + 1] - ak[0]) * inv_den[p];
-#pragma unroll
-      for (int p = 0; p < D; ++p)
-#pragma unroll
-        for (int r2 = 0; r2 < D; ++r2) xtx[p * D + r2] += xs[p] * xs[r2];
+      grp.sample(ak, ld[kk], inv_den);
     }
   }
-  if (active) {
-    const double std2 = ssq * A.inv_dof;
-    double V[D * D];
-    initial_covariance<D>(xtx, std2, A.width, V);
-#pragma unroll
-    for (int e = 0; e < D * D; ++e) A.V[e * A.C + i] = V[e];  // MCMC.py:266
-    A.std2[i] = std2;
-    A.ssq[i] = ssq;
-  }
+  grp.finish(A, active);
 }
 
 // float32 mode: the sampler compares sums of squares from float32 solves, so the initial SSq (computed by the

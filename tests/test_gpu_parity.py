@@ -304,6 +304,36 @@ def _run_pair(gpu, cpu, n_iters, C, q0, data, lo, hi, **kw):
     return gpu.mcmc_run(n_iters), cpu.mcmc_run(n_iters), rerun
 
 
+@pytest.mark.parametrize("d", [1, 3])
+def test_initial_covariance_from_stiff_and_ordinary_start_points(gpu_engine, cpu_engine, oracle_mod, d):
+    """The init kernels — one lane per trajectory, the chain's 1 + d lanes meeting at every output sample by lane shuffles —
+    from start points that span every integration tier: Dc down to 6, where the incremental tiers' guards trip and the lane
+    redoes the trip with full evaluations (a path no test reached before round 4; the lockstep kernel it replaced restored
+    the wrong state representation there), up to 6000.  Initial SSq and sigma^2_0 against the checker to 1e-9; the proposal
+    covariance on its own scale (d = 1: the forward-difference noise of MCMC.py:251 allows 2e-6 there; stiff start points
+    amplify it further and are held to 1e-3)."""
+    m = _models(oracle_mod, 500)
+    for e in (gpu_engine, cpu_engine):
+        e.set_model(m, 1)
+    data = synthetic_data(cpu_engine)
+    C = 777  # not a multiple of the 64 / 128 chains a workgroup's lane groups hold
+    rng = np.random.default_rng(9)
+    q0 = np.column_stack([np.exp(rng.uniform(np.log(6.0), np.log(6000.0), C)), rng.uniform(0.009, 0.014, C), rng.uniform(0.012, 0.018, C)])[:, :d]
+    lo, hi = [0.0, 0.005, 0.005][:d], [1e4, 0.02, 0.03][:d]
+    for e in (gpu_engine, cpu_engine):
+        e.mcmc_init(q0, data, lo, hi, seed=1, prior_len=3, fd_rel_step=1e-6 if d == 1 else 1e-4)
+    sg, sc = [np.asarray(x) for x in gpu_engine.get_state()], [np.asarray(x) for x in cpu_engine.get_state()]
+    assert np.isfinite(sg[1]).all() and np.isfinite(sg[3]).all()
+    np.testing.assert_allclose(sg[1], sc[1], rtol=RTOL)
+    np.testing.assert_allclose(sg[2], sc[2], rtol=RTOL)
+    sd = np.sqrt(np.diagonal(sc[3], axis1=1, axis2=2))
+    err = np.abs(sg[3] - sc[3]) / (sd[:, :, None] * sd[:, None, :])
+    ordinary = q0[:, 0] > 150.0
+    assert err[ordinary].max() < (2e-6 if d == 1 else 1e-4), err[ordinary].max()
+    assert err.max() < 1e-3, err.max()
+    assert (q0[:, 0] < 20.0).sum() > 50  # the stiff start points are really there
+
+
 @pytest.mark.parametrize("n,C,adapt", [(500, 300, "none"), (500, 130, "reference_dict"), (500, 130, "am"), (2000, 70, "none")])
 def test_mcmc_run_matches_oracle(gpu_engine, cpu_engine, oracle_mod, n, C, adapt):
     m = _models(oracle_mod, n)
