@@ -166,25 +166,45 @@ struct InitGroup {
         inv_den = 1.0 / (pq[p] * A.fd);  // perturbed value in the denominator, MCMC.py:264
       }
   }
-  // an output sample is complete: ak = this lane's acceleration sample, obs the observation (every lane of the group calls)
+  // the value lane `SRC` of this lane's group holds.  A group is an aligned pair or quad of lanes, so this is a DPP quad_perm move
+  // (two, for the two halves of a double) in the VALU — no trip through the LDS pipe as a general shuffle (ds_bpermute) takes
+  template <int SRC>
+  static __device__ __forceinline__ double from_lane(double v) {
+    constexpr int ctrl = G == 4 ? (SRC | SRC << 2 | SRC << 4 | SRC << 6) : (SRC | SRC << 2 | (2 + SRC) << 4 | (2 + SRC) << 6);
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), ctrl, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), ctrl, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+  }
+  template <int P>
+  __device__ __forceinline__ void gather(double x, double (&xs)[D]) const {
+    if constexpr (P < D) {
+      xs[P] = from_lane<P + 1>(x);
+      gather<P + 1>(x, xs);
+    }
+  }
+  // an output sample is complete: ak = this lane's acceleration sample, obs the observation (every lane of the group calls, in
+  // converged control flow).  Only the upper triangle of X^T X is accumulated; finish() mirrors it
   __device__ __forceinline__ void sample(double ak, double obs, double inv_den) {
-    const double ak0 = __shfl(ak, lane0, 64);
+    const double ak0 = from_lane<0>(ak);
     const double x = (ak - ak0) * inv_den;  // lane p + 1: the sensitivity to parameter p; lane 0: 0
     double xs[D];
-#pragma unroll
-    for (int p = 0; p < D; ++p) xs[p] = __shfl(x, lane0 + p + 1, 64);
+    gather<0>(x, xs);
     const double r = ak - obs;  // meaningful in lane 0 (the others accumulate values nobody reads)
     ssq = __builtin_fma(r, r, ssq);
 #pragma unroll
     for (int p = 0; p < D; ++p)
 #pragma unroll
-      for (int r2 = 0; r2 < D; ++r2) xtx[p * D + r2] = __builtin_fma(xs[p], xs[r2], xtx[p * D + r2]);
+      for (int r2 = p; r2 < D; ++r2) xtx[p * D + r2] = __builtin_fma(xs[p], xs[r2], xtx[p * D + r2]);
   }
   __device__ __forceinline__ void finish(const InitArgs &A, bool active) const {
     if (active && tr == 0) {
       const double std2 = ssq * A.inv_dof;
-      double V[D * D];
-      initial_covariance<D>(xtx, std2, A.width, V);
+      double V[D * D], M[D * D];
+#pragma unroll
+      for (int p = 0; p < D; ++p)
+#pragma unroll
+        for (int r2 = 0; r2 < D; ++r2) M[p * D + r2] = xtx[p <= r2 ? p * D + r2 : r2 * D + p];
+      initial_covariance<D>(M, std2, A.width, V);
 #pragma unroll
       for (int e = 0; e < D * D; ++e) A.V[e * A.C + chain] = V[e];  // MCMC.py:266
       A.std2[chain] = std2;
