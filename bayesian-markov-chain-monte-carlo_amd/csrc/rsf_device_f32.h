@@ -4,93 +4,415 @@
 // interface array, the sum of squares accumulator and the whole sampler logic (proposal, accept
 // test, sigma^2 update, adaptation, initial covariance) stay float64.
 //
-// In float32 the hardware transcendentals are one instruction each (v_log_f32 = log2, v_exp_f32 =
-// 2^x, v_rcp_f32; ~1 ulp), so every RK4 stage is evaluated in full — no incremental series — and
-// the constants are pre-scaled for base 2.  The acceleration sample is formed from the step's
-// velocity INCREMENT, not from the difference of two velocities near V_ref, which would lose
-// ~4 digits in float32.  Same rescaled state as the float64 path — ms = mu/k', x = V_ref theta/Dc — and the same
-// regrouping of the RHS around w = v/V_ref with dV/dt in units of vk (rsf_device.h, rhs_tight); the two state components
-// and their derivatives are carried as packed pairs (v_pk_fma_f32).
+// Same rescaled state as the float64 path — ms = mu/k', x = V_ref theta/Dc — and the same regrouping of the RHS around
+// w = v/V_ref with dV/dt in units of vk (rsf_device.h).  The acceleration sample is formed from the step's velocity
+// INCREMENT, not from the difference of two velocities near V_ref, which would lose ~4 digits in float32.
+//
+// What a CHAIN computes (a function of its own parameters and trajectory only — restated step for step by
+// oracle/rsf_oracle.c::solve_f32; what the wave around it does is a speed decision and changes no result):
+//
+//   * It starts in the INCREMENTAL form (round 4; rk4_incr): the state is (w, Rh = (h/2Dc)/x), ms rides along, and every
+//     stage of an RK4 step reaches its (w, 1/x) from the step's start point by short series — log1p to rho^2/2, expm1 to
+//     dlt^3/6, 1/x' = (1/x)(1 - rho + rho^2) — the float64 TIGHT tier's step (rsf_device.h, rk4_tight) with one expm1 term
+//     fewer and the operations ordered for a short dependency chain (incr): NO transcendental instruction.  (Until round 4 every stage was a full evaluation with v_log_f32 / v_exp_f32 /
+//     v_rcp_f32 — 12 per chain-step at half rate, a third of the step's issue cycles.)  In float32 the series are good
+//     to < 1e-9 relative for |rho| < 2^-9, |dlt| < 2^-6: one tier reaches further than the float64 path's three.
+//   * A step whose END increments leave |rho| < 2^-10, |dlt| < 2^-7 (a factor of two inside the series' range, for the
+//     stages of the step, whose increments are of the end increments' size) is not taken incrementally: from that step
+//     on, to the end of the solve, the chain takes FULL evaluations at every stage (rk4_full: the hardware
+//     transcendentals, the form every chain had until round 4), starting from (ms, x = hhd/Rh) at that step's start.
+//     NaN increments pass the test, as in the float64 path: a dead trajectory ends in a non-finite sum of squares.
+//   * No resync: in float32 ms ~ 6 Dc carries an absolute rounding error of 2^-12 .. 2^-11 per step, which a
+//     re-evaluation of w from it would inject (1e-4 relative over a solve), whereas w carried by its own products drifts
+//     by 6e-8 sqrt(steps).  (w, x) is a closed system; ms is carried for the switch to full evaluations alone.
+//
+// Two forms of the same arithmetic: V = float (one chain per lane: forward kernel, initial SSq) and V = a packed pair
+// (TWO chains per lane: the sampler; each instruction a v_pk_*_f32 that advances both — 2x the work per issue slot, which
+// is what float32 can give on this part, plain v_fma_f32 runs at the float64 rate).  Operation for operation identical
+// (v_pk_fma_f32 is an IEEE fma per half, implicit contraction is off), so a chain's result does not depend on the form.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 #include "rsf_device.h"
+#include "rsf_f32_trip.inc"  // generated: the two-chain incremental trip as scheduled assembly (tools/gen_f32_trip.py)
 
 namespace rsf {
 namespace f32 {
 
-// two floats in one 64-bit register pair: (d(ms)/dt, d(x)/dt) of a stage travel together, so that the stage inputs, the
-// RK4 combination and the damping correction are v_pk_fma_f32 / v_pk_mul_f32 — one instruction for both components
 typedef float float2v __attribute__((ext_vector_type(2)));
 
-__device__ __forceinline__ float2v pk_fma(float2v a, float2v b, float2v c) { return __builtin_elementwise_fma(a, b, c); }
+template <typename V>
+struct Vt;
+template <>
+struct Vt<float> {
+  static constexpr int N = 1;
+  static __device__ __forceinline__ float splat(float s) { return s; }
+  static __device__ __forceinline__ float get(float v, int) { return v; }
+  static __device__ __forceinline__ void set(float &v, int, float s) { v = s; }
+};
+template <>
+struct Vt<float2v> {
+  static constexpr int N = 2;
+  static __device__ __forceinline__ float2v splat(float s) { return float2v{s, s}; }
+  static __device__ __forceinline__ float get(float2v v, int i) { return v[i]; }
+  static __device__ __forceinline__ void set(float2v &v, int i, float s) { v[i] = s; }
+};
 
+template <typename V>
+__device__ __forceinline__ V vfma(V a, V b, V c) { return __builtin_elementwise_fma(a, b, c); }
+// the hardware transcendentals, once per chain
+template <typename V>
+__device__ __forceinline__ V vlog2(V x) {
+  if constexpr (Vt<V>::N == 1) return __builtin_amdgcn_logf(x);
+  else return V{__builtin_amdgcn_logf(x.x), __builtin_amdgcn_logf(x.y)};
+}
+template <typename V>
+__device__ __forceinline__ V vexp2(V x) {
+  if constexpr (Vt<V>::N == 1) return __builtin_amdgcn_exp2f(x);
+  else return V{__builtin_amdgcn_exp2f(x.x), __builtin_amdgcn_exp2f(x.y)};
+}
+template <typename V>
+__device__ __forceinline__ V vrcp(V x) {
+  if constexpr (Vt<V>::N == 1) return __builtin_amdgcn_rcpf(x);
+  else return V{__builtin_amdgcn_rcpf(x.x), __builtin_amdgcn_rcpf(x.y)};
+}
+
+// the guard of the incremental step (see the header): |rho| and |dlt| of a step's end increment
+constexpr float kRhoMax = 0x1p-10f, kDltMax = 0x1p-7f;
+
+// per-chain constants of a solve, float64 expressions rounded once
 struct Lane32 {
+  // full evaluation: the exponent pre-scaled to base 2 (v_exp_f32 is 2^x, v_log_f32 is log2)
   float kia2;    // (k'/a) log2(e)
   float tc2;     // -(mu_ref/a) log2(e)
   float boa;     // b/a
   float beta;    // (V_ref b/Dc)/k' = 10 b V_ref: b/theta dtheta/dt in units of k' (rsf_device.h, struct Lane)
   float c3;      // beta - V_ref
   float kvk;     // (k1/k') vk = k1 V_ref/a: radiation damping
-  float vref;
   float cv;      // (h/6)/delta_t * vk: acceleration sample = cv * (weighted sum of w g over the interval's steps)
-  float2v chh, ch, ch6;  // (h/2, (h/2) V_ref/Dc), (h, h V_ref/Dc), (h/6, (h/6) V_ref/Dc): step fractions of (ms, x)
+  float hhd, hd, h6d;   // (h/2, h, h/6) V_ref/Dc: step fractions of x
+  // incremental step (natural exponent)
+  float khh, kh, kh6;   // (k'/a)(h/2, h, h/6): d(mu)/a of a stage / of the step from the ms derivative
+  float nhboa;          // -b/2a: (b/a) log1p(rho) = rho (b/a - (b/2a) rho)
+  float bh;             // beta/hhd: (beta/x) d1 = bh (1 + q) d1' with d1' = Rh d1
+  float w0;             // w(0) = exp((mu(0) - mu_ref)/a) (x(0) = 1), evaluated in float64
+  float ms0;            // ms(0) = mu(0)/k'
+  // the same for every chain
+  float vref, hh, h, h6;
 };
 
 __device__ __forceinline__ Lane32 make_lane32(double dc, double a, double b, const Consts &K) {
   const double log2e = 1.4426950408889634074;
   const double inv_a = 1.0 / a, inv_dc = 1.0 / dc, kprime = (1e-2 * 10) / dc;
   const double vdc = K.V_ref * inv_dc;  // dx/dt = (V_ref/Dc) (1 - w x)
+  const double beta = b * K.V_ref * (1.0 / (1e-2 * 10));
   Lane32 L;
   L.kia2 = (float)(kprime * inv_a * log2e);
   L.tc2 = (float)(-K.mu_ref * inv_a * log2e);
   L.boa = (float)(b * inv_a);
-  L.beta = (float)(b * K.V_ref * (1.0 / (1e-2 * 10)));
-  L.c3 = (float)(b * K.V_ref * (1.0 / (1e-2 * 10)) - K.V_ref);
+  L.beta = (float)beta;
+  L.c3 = (float)(beta - K.V_ref);
   L.kvk = (float)(K.k1 * K.V_ref * inv_a);
-  L.vref = (float)K.V_ref;
   L.cv = (float)(K.cacc * (K.V_ref * inv_a * kprime));
-  L.chh = float2v{(float)K.hh, (float)(K.hh * vdc)};
-  L.ch = float2v{(float)K.h, (float)(K.h * vdc)};
-  L.ch6 = float2v{(float)K.h6, (float)(K.h6 * vdc)};
+  L.hhd = (float)(K.hh * vdc);
+  L.hd = (float)(K.h * vdc);
+  L.h6d = (float)(K.h6 * vdc);
+  L.khh = (float)(kprime * inv_a * K.hh);
+  L.kh = (float)(kprime * inv_a * K.h);
+  L.kh6 = (float)(kprime * inv_a * K.h6);
+  L.nhboa = (float)(-0.5 * (b * inv_a));
+  L.bh = (float)(beta / (K.hh * vdc));
+  L.w0 = (float)fm::exp((K.mu0 - K.mu_ref) * inv_a);
+  L.ms0 = (float)(K.mu0 / kprime);
+  L.vref = (float)K.V_ref;
+  L.hh = (float)K.hh;
+  L.h = (float)K.h;
+  L.h6 = (float)K.h6;
   return L;
 }
 
-// The RHS at (ms, x) = s, RateStateModel.py:318-355 in the float64 path's regrouping (rsf_device.h, rhs_tight): with
+template <typename V>
+struct LaneV {
+  V kia2, tc2, boa, beta, c3, kvk, cv, hhd, hd, h6d, khh, kh, kh6, nhboa, bh, vref, hh, h, h6;
+};
+
+template <typename V>
+__device__ __forceinline__ LaneV<V> make_lanev(const Lane32 (&S)[Vt<V>::N]) {
+  typedef Vt<V> T;
+  LaneV<V> L;
+#define RSF_F32_FIELD(f)                                   \
+  L.f = T::splat(S[0].f);                                  \
+  if constexpr (T::N == 2) T::set(L.f, 1, S[1].f);
+  RSF_F32_FIELD(kia2) RSF_F32_FIELD(tc2) RSF_F32_FIELD(boa) RSF_F32_FIELD(beta) RSF_F32_FIELD(c3) RSF_F32_FIELD(kvk)
+  RSF_F32_FIELD(cv) RSF_F32_FIELD(hhd) RSF_F32_FIELD(hd) RSF_F32_FIELD(h6d) RSF_F32_FIELD(khh) RSF_F32_FIELD(kh)
+  RSF_F32_FIELD(kh6) RSF_F32_FIELD(nhboa) RSF_F32_FIELD(bh)
+#undef RSF_F32_FIELD
+  // the same value in every lane: held in SGPRs (a packed instruction reads one scalar pair)
+  auto uniform = [](float f) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, f))); };
+  L.vref = T::splat(uniform(S[0].vref)); L.hh = T::splat(uniform(S[0].hh)); L.h = T::splat(uniform(S[0].h)); L.h6 = T::splat(uniform(S[0].h6));
+  return L;
+}
+
+// ---------------------------------------------------------------------------------------------
+// FULL evaluation step.  The RHS at (ms, x), RateStateModel.py:318-355 in the float64 path's regrouping: with
 // w = v/V_ref = 2^(kia2 ms + tc2 - (b/a) log2 x) the bracket of dV/dt = vk w g is linear in w,
 //     g = (V_l - beta/x) + (beta - V_ref) w,
 // and the damping pass (RateStateModel.py:349-353) subtracts the same (kvk w) g from d(ms)/dt and from g.
-// → d = (d(ms)/dt, dtheta/dt) and w g, the stage's dV/dt in units of vk.
-template <bool DAMP>
-__device__ __forceinline__ float rhs32(float2v s, float vl, const Lane32 &L, float2v &d) {
+// → d0 = d(ms)/dt, d1 = dtheta/dt and w g, the stage's dV/dt in units of vk.
+// ---------------------------------------------------------------------------------------------
+template <bool DAMP, typename V>
+__device__ __forceinline__ V rhs_full(V ms, V x, float vl, const LaneV<V> &L, V &d0, V &d1) {
 #pragma clang fp contract(off)  // every fused multiply-add of this path is written out: one-chain and two-chain forms round alike
-  const float lg = __builtin_amdgcn_logf(s.y), rx = __builtin_amdgcn_rcpf(s.y);
-  const float w = __builtin_amdgcn_exp2f(__builtin_fmaf(-L.boa, lg, __builtin_fmaf(s.x, L.kia2, L.tc2)));
-  const float t1 = __builtin_fmaf(-L.beta, rx, vl);
-  d.x = __builtin_fmaf(-L.vref, w, vl);   // V_l - v
-  d.y = __builtin_fmaf(-w, s.y, 1.0f);    // 1 - w x   (the two halves of one register pair: no move to form the pair)
-  float g = __builtin_fmaf(L.c3, w, t1);
+  const V lg = vlog2(x), rx = vrcp(x);
+  const V w = vexp2(vfma(-L.boa, lg, vfma(ms, L.kia2, L.tc2)));
+  const V vl2 = Vt<V>::splat(vl), one = Vt<V>::splat(1.0f);
+  const V t1 = vfma(-L.beta, rx, vl2);
+  d0 = vfma(-L.vref, w, vl2);   // V_l - v
+  d1 = vfma(-w, x, one);        // 1 - w x
+  V g = vfma(L.c3, w, t1);
   if (DAMP) {
-    const float kw = L.kvk * w;
-    d.x = __builtin_fmaf(-kw, g, d.x);
-    g = __builtin_fmaf(-kw, g, g);
+    const V kw = L.kvk * w;
+    d0 = vfma(-kw, g, d0);
+    g = vfma(-kw, g, g);
   }
   return w * g;
 }
 
 // one RK4 step; returns the weighted sum k1 + 2 k2 + 2 k3 + k4 of dV/dt in units of vk
-template <bool DAMP>
-__device__ __forceinline__ float rk4_step32(float2v &s, float vl0, float vlm, float vl1, const Lane32 &L) {
-#pragma clang fp contract(off)  // every fused multiply-add of this path is written out: one-chain and two-chain forms round alike
-  float2v a, b, c, e;
-  const float wa = rhs32<DAMP>(s, vl0, L, a);
-  const float wb = rhs32<DAMP>(pk_fma(L.chh, a, s), vlm, L, b);
-  const float wc = rhs32<DAMP>(pk_fma(L.chh, b, s), vlm, L, c);
-  const float we = rhs32<DAMP>(pk_fma(L.ch, c, s), vl1, L, e);
-  const float2v two = {2.0f, 2.0f};
-  s = pk_fma(L.ch6, pk_fma(two, b + c, a + e), s);
-  return __builtin_fmaf(2.0f, wb + wc, wa + we);
+template <bool DAMP, typename V>
+__device__ __forceinline__ V rk4_full(V &ms, V &x, float vl0, float vlm, float vl1, const LaneV<V> &L) {
+#pragma clang fp contract(off)
+  V a0, a1, b0, b1, c0, c1, e0, e1;
+  const V wa = rhs_full<DAMP>(ms, x, vl0, L, a0, a1);
+  const V wb = rhs_full<DAMP>(vfma(L.hh, a0, ms), vfma(L.hhd, a1, x), vlm, L, b0, b1);
+  const V wc = rhs_full<DAMP>(vfma(L.hh, b0, ms), vfma(L.hhd, b1, x), vlm, L, c0, c1);
+  const V we = rhs_full<DAMP>(vfma(L.h, c0, ms), vfma(L.hd, c1, x), vl1, L, e0, e1);
+  const V two = Vt<V>::splat(2.0f);
+  ms = vfma(L.h6, vfma(two, b0 + c0, a0 + e0), ms);
+  x = vfma(L.h6d, vfma(two, b1 + c1, a1 + e1), x);
+  return vfma(two, wb + wc, wa + we);
+}
+
+// ---------------------------------------------------------------------------------------------
+// INCREMENTAL step (rsf_device.h, rk4_tight, in float32).  Rh = hhd/x is the state; every theta derivative of the step
+// is carried scaled by it, d1' = Rh (1 - w x) = Rh - w (Rh x_s) with Rh x_s = hhd + c_s d1'_prev — so rho = dx/x of a
+// half-step stage IS the previous stage's d1', of the full-step stage twice it, of the step's end a third of the
+// weighted sum — and (beta/x_s) d1 = bh (1 + q) d1'.
+//   d0 = V_l - V_ref w,   g = d0 - brx d1'   (+ the damping pass),   the stage's dV/dt = vk w g.
+// ---------------------------------------------------------------------------------------------
+template <bool DAMP, typename V>
+__device__ __forceinline__ void rhs_incr(V w, V xr, V Rh, V vl2, V brx, const LaneV<V> &L, V &d0, V &d1, V &g) {
+#pragma clang fp contract(off)
+  d1 = vfma(-w, xr, Rh);
+  d0 = vfma(-L.vref, w, vl2);
+  g = vfma(-brx, d1, d0);
+  if (DAMP) {
+    const V kw = L.kvk * w;
+    d0 = vfma(-kw, g, d0);
+    g = vfma(-kw, g, g);
+  }
+}
+
+// (w', 1 + q = x/x') at the point reached from the step's start point (w0, x) by rho = dx/x and d(mu)/a = kd d0:
+//   dlt = kd d0 - (b/a) log1p(rho),  w' = w0 exp(dlt),  1/x' = (1/x)(1 + q)
+// written for a SHORT DEPENDENCY CHAIN, not for few operations: at one wave per SIMD (config 5's shape) a dependent packed
+// instruction issues 9.7 cycles after its producer, an independent one after 4 (tools/microbench_pk_f32.hip), and d0 — the
+// damped d(ms)/dt — is the last value of a stage to arrive.  rho P is formed beside it, so dlt is ONE operation after d0;
+// w' = w0 (1 + dlt) + dlt^2 (w0/2 + (w0/6) dlt) is two levels after dlt (Horner: three).  w02 = w0/2, w06 = w0/6: per step.
+template <typename V>
+__device__ __forceinline__ void incr(V rho, V kd, V d0, const LaneV<V> &L, V w0, V w02, V w06, V &w, V &q, V &dlt) {
+#pragma clang fp contract(off)
+  const V rP = rho * vfma(rho, L.nhboa, L.boa);
+  dlt = vfma(kd, d0, -rP);
+  const V d2 = dlt * dlt, A = vfma(dlt, w0, w0), B = vfma(dlt, w06, w02);
+  w = vfma(d2, B, A);
+  q = vfma(rho, rho, -rho);
+}
+
+// one RK4 step of the incremental form: (w, Rh, ms) → the step's end; rho_end / dlt_end = the end increment (the guard's input)
+template <bool DAMP, typename V>
+__device__ __forceinline__ V rk4_incr(V &w_io, V &Rh_io, V &ms_io, float vl0, float vlm, float vl1, const LaneV<V> &L, V &rho_end,
+                                      V &dlt_end) {
+#pragma clang fp contract(off)
+  typedef Vt<V> T;
+  const V w0 = w_io, Rh = Rh_io, vm = T::splat(vlm), two = T::splat(2.0f), third = T::splat(1.0f / 3.0f);
+  const V w02 = w0 * T::splat(0.5f), w06 = w0 * T::splat(1.0f / 6.0f);
+  V a0, a1, ga, b0, b1, gb, c0, c1, gc, e0, e1, ge, w, q, dlt;
+  rhs_incr<DAMP>(w0, L.hhd, Rh, T::splat(vl0), L.bh, L, a0, a1, ga);
+  V sv = w0 * ga;  // k1 + k4 of dV/dt (in units of vk), and k2 + k3 below
+  incr(a1, L.khh, a0, L, w0, w02, w06, w, q, dlt);
+  rhs_incr<DAMP>(w, vfma(L.hhd, a1, L.hhd), Rh, vm, vfma(L.bh, q, L.bh), L, b0, b1, gb);
+  V sm = w * gb;
+  incr(b1, L.khh, b0, L, w0, w02, w06, w, q, dlt);
+  rhs_incr<DAMP>(w, vfma(L.hhd, b1, L.hhd), Rh, vm, vfma(L.bh, q, L.bh), L, c0, c1, gc);
+  sm = vfma(w, gc, sm);
+  const V T0 = vfma(two, b0 + c0, a0), T13 = vfma(two, b1 + c1, a1) * third;  // the weighted sums but for stage 4: ready before it
+  incr(c1 + c1, L.kh, c0, L, w0, w02, w06, w, q, dlt);
+  rhs_incr<DAMP>(w, vfma(L.hd, c1, L.hhd), Rh, T::splat(vl1), vfma(L.bh, q, L.bh), L, e0, e1, ge);
+  sv = vfma(w, ge, sv);
+  const V t0 = T0 + e0;
+  rho_end = vfma(e1, third, T13);  // (h/6Dc)/x times the unscaled sum
+  incr(rho_end, L.kh6, t0, L, w0, w02, w06, w, q, dlt_end);
+  ms_io = vfma(L.h6, t0, ms_io);
+  w_io = w;
+  Rh_io = vfma(Rh, q, Rh);
+  return vfma(two, sm, sv);
+}
+
+__device__ __forceinline__ bool step_fits(float rho, float dlt) {  // NaN fits (header)
+  return !(__builtin_fabsf(rho) >= kRhoMax) && !(__builtin_fabsf(dlt) >= kDltMax);
+}
+
+// State of the chains of a lane.  full[c]: chain c takes full evaluations — (ms, x) is its state, (w, Rh) stale; otherwise
+// (w, Rh, ms) is, x stale.
+template <typename V>
+struct State32 {
+  V w, Rh, ms, x;
+  bool full[Vt<V>::N];
+};
+
+// One step of every chain of the lane by the chain's own rule (header): the definition the straight-line trips below are a
+// fast path of, and the step of the loops that are not unrolled (substeps > 1, the tail of a chunk, the replay of a trip in
+// which a chain left the incremental form).
+template <bool DAMP, typename V>
+__device__ __forceinline__ V step_any(State32<V> &s, float vl0, float vlm, float vl1, const LaneV<V> &L) {
+#pragma clang fp contract(off)
+  typedef Vt<V> T;
+  V dv = T::splat(0.0f);
+  bool some_incr = false;
+#pragma unroll
+  for (int c = 0; c < T::N; ++c) some_incr |= !s.full[c];
+  if (some_incr) {
+    V w1 = s.w, Rh1 = s.Rh, ms1 = s.ms, rho, dlt;
+    const V dvi = rk4_incr<DAMP>(w1, Rh1, ms1, vl0, vlm, vl1, L, rho, dlt);
+#pragma unroll
+    for (int c = 0; c < T::N; ++c)
+      if (!s.full[c]) {
+        if (step_fits(T::get(rho, c), T::get(dlt, c))) {
+          T::set(s.w, c, T::get(w1, c)); T::set(s.Rh, c, T::get(Rh1, c)); T::set(s.ms, c, T::get(ms1, c));
+          T::set(dv, c, T::get(dvi, c));
+        } else {  // this step and every later one by full evaluations, from (ms, x = hhd/Rh) at this step's start; one rounding
+          T::set(s.x, c, (float)((double)T::get(L.hhd, c) / (double)T::get(s.Rh, c)));
+          s.full[c] = true;
+        }
+      }
+  }
+  bool some_full = false;
+#pragma unroll
+  for (int c = 0; c < T::N; ++c) some_full |= s.full[c];
+  if (some_full) {
+    V msf = s.ms, xf = s.x;
+    const V dvf = rk4_full<DAMP>(msf, xf, vl0, vlm, vl1, L);
+#pragma unroll
+    for (int c = 0; c < T::N; ++c)
+      if (s.full[c]) {
+        T::set(s.ms, c, T::get(msf, c)); T::set(s.x, c, T::get(xf, c));
+        T::set(dv, c, T::get(dvf, c));
+      }
+  }
+  return dv;
+}
+
+// byte address in LDS of a pointer into the workgroup's shared array (for the ds_read instructions of the assembly trip)
+__device__ __forceinline__ unsigned lds_addr(const float *p) {
+  return (unsigned)(size_t)(const __attribute__((address_space(3))) float *)p;
+}
+
+// Output of a solve: the sums of squares of the lane's chains and (one-chain form) the trajectory.
+template <bool WANT_SSQ, bool WANT_ACC, typename V>
+struct Out32 {
+  double ssq[Vt<V>::N];
+  double *acc_out;
+  int64_t stride;
+  V cv;
+  // sample k of the series (index kk of the staged chunk `ld`): dv = the interval's weighted sum of dV/dt in units of vk
+  __device__ __forceinline__ void emit(int k, int kk, const float *ld, V dv, bool store) {
+#pragma clang fp contract(off)
+    typedef Vt<V> T;
+    const V ak = dv * cv;  // RateStateModel.py:388, from the interval's velocity increment
+    if (WANT_ACC) {
+      if (store) acc_out[(int64_t)k * stride] = (double)T::get(ak, 0);
+    }
+    if (WANT_SSQ) {
+      const float obs = ld[kk];
+#pragma unroll
+      for (int c = 0; c < T::N; ++c) {
+        const double r = (double)(T::get(ak, c) - obs);
+        ssq[c] = __builtin_fma(r, r, ssq[c]);
+      }
+    }
+  }
+};
+
+// NU steps of every chain of the lane, one step per output sample (samples k .. k + NU - 1, chunk indices kk ..), as
+// straight-line code; which code runs is decided per WAVE (all chains incremental / all full / both), what a chain
+// computes is step_any's rule.  Every sample is emitted where it is computed — the sums of squares of the trip's start are
+// kept, so that a chain's sum holds the samples of the form the chain is in, added in series order whatever ran.
+template <bool DAMP, int NU, bool WANT_SSQ, bool WANT_ACC, typename V>
+__device__ __forceinline__ void trip32(State32<V> &s, const float *v, const float *ld, int k, int kk, const LaneV<V> &L,
+                                       Out32<WANT_SSQ, WANT_ACC, V> &out) {
+#pragma clang fp contract(off)
+  typedef Vt<V> T;
+  bool some_incr = false, some_full = false;
+#pragma unroll
+  for (int c = 0; c < T::N; ++c) { some_incr |= !s.full[c]; some_full |= s.full[c]; }
+  const bool wave_incr = __any(some_incr), wave_full = __any(some_full);
+  const V w_s = s.w, Rh_s = s.Rh, ms_s = s.ms;
+  double ssq_s[T::N];
+#pragma unroll
+  for (int c = 0; c < T::N; ++c) ssq_s[c] = out.ssq[c];
+  bool redo = false;
+  if (wave_incr) {
+    bool left = false;  // may a chain of this lane that was incremental have met a step that does not fit?
+    if constexpr (T::N == 2) {
+      // The sampler's form: the NU steps, the emission of their samples and the trip's guard sums as ONE statement of
+      // scheduled assembly (rsf_f32_trip.inc; why the order of issue is not left to the compiler: tools/gen_f32_trip.py).
+      // It works in the solve's private register file — v[RSF_F32_TRIP_COMPILER_VGPRS .. 255], which the kernel's
+      // amdgpu_num_vgpr keeps the compiler out of — where solve32v parked the chains' constants.
+      // The guard: sums of squares of the steps' end increments (two packed operations per step).  Below the squared
+      // bounds, every step fitted (each square is at most the sum; squaring and adding round monotonically, the bounds are
+      // powers of two); otherwise — a NaN sum included — the trip is replayed step by step under step_fits itself.
+      static_assert(NU == RSF_F32_TRIP_STEPS && WANT_SSQ && !WANT_ACC, "rsf_f32_trip.inc: eight steps, sums of squares only");
+      V g2r, g2d;
+      const unsigned vv_addr = lds_addr(v), ob_addr = lds_addr(ld + kk);
+      if constexpr (DAMP) RSF_F32_TRIP_DAMPED(s.w, s.Rh, s.ms, out.ssq[0], out.ssq[1], g2r, g2d, vv_addr, ob_addr);
+      else RSF_F32_TRIP_UNDAMPED(s.w, s.Rh, s.ms, out.ssq[0], out.ssq[1], g2r, g2d, vv_addr, ob_addr);
+#pragma unroll
+      for (int c = 0; c < T::N; ++c)
+        left |= !s.full[c] && !(T::get(g2r, c) < kRhoMax * kRhoMax && T::get(g2d, c) < kDltMax * kDltMax);
+    } else {
+      bool fits = true;
+#pragma unroll
+      for (int j = 0; j < NU; ++j) {
+        V rho, dlt;
+        const V dv = rk4_incr<DAMP>(s.w, s.Rh, s.ms, v[2 * j], v[2 * j + 1], v[2 * j + 2], L, rho, dlt);
+        out.emit(k + j, kk + j, ld, dv, !s.full[0]);
+        fits = fits && step_fits(T::get(rho, 0), T::get(dlt, 0));
+      }
+      left = !s.full[0] && !fits;
+    }
+    redo = __any(left);
+  }
+  if (redo) {  // rare: the trip again from its start, step by step (identical results for the chains whose steps all fitted)
+    s.w = w_s; s.Rh = Rh_s; s.ms = ms_s;
+#pragma unroll
+    for (int c = 0; c < T::N; ++c) out.ssq[c] = ssq_s[c];
+#pragma unroll 1
+    for (int j = 0; j < NU; ++j) out.emit(k + j, kk + j, ld, step_any<DAMP>(s, v[2 * j], v[2 * j + 1], v[2 * j + 2], L), true);
+  } else if (wave_full) {
+    double ssq_i[T::N];  // the incremental chains' sums are final; the full chains' start again from the trip's start
+#pragma unroll
+    for (int c = 0; c < T::N; ++c) { ssq_i[c] = out.ssq[c]; out.ssq[c] = ssq_s[c]; }
+    V msf = ms_s, xf = s.x;  // (the incremental trip advanced ms of every chain; the full chains' ms is the trip's start value)
+#pragma unroll
+    for (int j = 0; j < NU; ++j) out.emit(k + j, kk + j, ld, rk4_full<DAMP>(msf, xf, v[2 * j], v[2 * j + 1], v[2 * j + 2], L), s.full[0]);
+#pragma unroll
+    for (int c = 0; c < T::N; ++c) {
+      if (s.full[c]) { T::set(s.ms, c, T::get(msf, c)); T::set(s.x, c, T::get(xf, c)); }
+      else out.ssq[c] = ssq_i[c];
+    }
+  }
 }
 
 // LDS layout (floats): [ vl : 2*S*kc+1 ][ data : kc ]; all threads of the workgroup must call it.
@@ -108,143 +430,46 @@ __device__ __forceinline__ void stage_chunk32(float *lds, const Consts &K, int k
   __syncthreads();
 }
 
-// S1: one step per output sample (the BASELINE configs) — the sample loop is then unrolled eight-fold into straight-line
-// code with the eight observations read ahead of the arithmetic, so that loop control, LDS addressing and the LDS
-// latency are paid once per eight steps (the float64 path's trip structure; a wave with one or two resident peers
-// cannot hide them otherwise).
-template <bool DAMP, bool WANT_SSQ, bool WANT_ACC, bool S1>
-__device__ __forceinline__ void integrate_chunk32(const float *lds, const Consts &K, const Lane32 &L, int k0, int kn,
-                                                  float2v &st, double &ssq, double *acc_out, int64_t stride) {
-#pragma clang fp contract(off)  // every fused multiply-add of this path is written out: one-chain and two-chain forms round alike
-  const float *ld = lds + lds_data_offset32(K);
-  auto emit = [&](int kk, float dv, float obs) {
-    const float ak = dv * L.cv;  // RateStateModel.py:388, from the interval's velocity increment
-    if (WANT_ACC) acc_out[(int64_t)(k0 + kk) * stride] = (double)ak;
-    if (WANT_SSQ) {
-      const double r = (double)(ak - obs);
-      ssq = __builtin_fma(r, r, ssq);
-    }
-  };
-  int kk = 0;
-  if (S1) {
-    constexpr int NU = 8;
-    for (; kk + NU <= kn; kk += NU) {
-      const float *v = lds + 2 * kk;
-      float obs[NU], dv[NU];
+// Forward solve of the lane's chains (which share the observation series: they belong to the workgroup's group).
+// active[c] = false: the slot integrates a harmless default point and its results are not used.
+// S = 1 (the BASELINE configs): eight steps per trip, the eight observations read ahead of the arithmetic, so that loop
+// control, LDS addressing and the LDS latency are paid once per eight steps.
+template <bool DAMP, bool WANT_SSQ, bool WANT_ACC, typename V>
+__device__ __forceinline__ void solve32v(float *lds, const Consts &K, bool resident, const bool (&active)[Vt<V>::N],
+                                         const double (&dc)[Vt<V>::N], const double (&a)[Vt<V>::N], const double (&b)[Vt<V>::N],
+                                         double (&ssq)[Vt<V>::N], double *acc_out, int64_t stride) {
+#pragma clang fp contract(off)
+  typedef Vt<V> T;
+  constexpr int N = T::N;
+  static_assert(!WANT_ACC || N == 1, "trajectories are written by the one-chain form");
+  Lane32 S[N];
+  bool any = false;
 #pragma unroll
-      for (int j = 0; j < NU; ++j) obs[j] = WANT_SSQ ? ld[kk + j] : 0.0f;
-#pragma unroll
-      for (int j = 0; j < NU; ++j) dv[j] = rk4_step32<DAMP>(st, v[2 * j], v[2 * j + 1], v[2 * j + 2], L);
-#pragma unroll
-      for (int j = 0; j < NU; ++j) emit(kk + j, dv[j], obs[j]);
-    }
+  for (int c = 0; c < N; ++c) {
+    S[c] = make_lane32(active[c] ? dc[c] : 1000.0, active[c] ? a[c] : K.a_def, active[c] ? b[c] : K.b_def, K);
+    any |= active[c];
   }
-  int j = 2 * K.S * kk;
-  for (; kk < kn; ++kk) {
-    float dv = 0.0f;
-    for (int sub = 0; sub < K.S; ++sub, j += 2) dv += rk4_step32<DAMP>(st, lds[j], lds[j + 1], lds[j + 2], L);
-    emit(kk, dv, WANT_SSQ ? ld[kk] : 0.0f);
+  const LaneV<V> L = make_lanev<V>(S);
+  if constexpr (N == 2) RSF_F32_TRIP_SETUP(L);  // the constants of the assembly trip → the private register file (trip32)
+  State32<V> st;
+  st.x = T::splat(1.0f);  // x = V_ref theta(0)/Dc = 1 with theta(0) = Dc/V_ref
+  st.Rh = L.hhd;
+#pragma unroll
+  for (int c = 0; c < N; ++c) {
+    T::set(st.w, c, S[c].w0);
+    T::set(st.ms, c, S[c].ms0);
+    st.full[c] = false;
   }
-}
-
-template <bool DAMP, bool WANT_SSQ, bool WANT_ACC>
-__device__ __forceinline__ double solve32(float *lds, const Consts &K, bool resident, bool active, double dc, double a,
-                                          double b, double *acc_out, int64_t stride) {
-  const Lane32 L = make_lane32(dc, a, b, K);
-  float2v st = {(float)(K.mu0 / ((1e-2 * 10) / dc)), 1.0f};  // (ms, x); x = V_ref theta(0)/Dc = 1 with theta(0) = Dc/V_ref
-  double ssq = 0.0;
-  if (WANT_SSQ && active) {
+  Out32<WANT_SSQ, WANT_ACC, V> out;
+  out.acc_out = acc_out; out.stride = stride; out.cv = L.cv;
+#pragma unroll
+  for (int c = 0; c < N; ++c) out.ssq[c] = 0.0;
+  if (WANT_SSQ && any) {
     const double d0 = (double)(float)K.data[0];
-    ssq = d0 * d0;
+#pragma unroll
+    for (int c = 0; c < N; ++c) out.ssq[c] = d0 * d0;
   }
-  if (WANT_ACC && active) acc_out[0] = 0.0;
-  for (int k0 = 1; k0 < K.nout; k0 += K.kc) {
-    const int kn = min(K.kc, K.nout - k0);
-    if (!resident) stage_chunk32(lds, K, k0, kn);
-    if (active) {
-      if (K.S == 1) integrate_chunk32<DAMP, WANT_SSQ, WANT_ACC, true>(lds, K, L, k0, kn, st, ssq, acc_out, stride);
-      else integrate_chunk32<DAMP, WANT_SSQ, WANT_ACC, false>(lds, K, L, k0, kn, st, ssq, acc_out, stride);
-    }
-  }
-  return ssq;
-}
-
-// ---------------------------------------------------------------------------------------------
-// TWO chains per lane (the float32 sampler kernel): every quantity of the solve is a packed pair {chain A, chain B}, so
-// each arithmetic instruction is a v_pk_*_f32 that advances both chains — 2x the work per issue slot, which is what
-// float32 can give on this part (plain v_fma_f32 runs at the float64 rate).  Operation for operation the same
-// arithmetic as the one-chain functions above (v_pk_fma_f32 is an IEEE fma per half), so a chain's result does not
-// depend on which form integrated it (tested: the sampler against the forward kernel and the float32 restatement).
-// The three transcendentals per stage are issued once per chain.
-// ---------------------------------------------------------------------------------------------
-struct Lane32x2 {
-  float2v kia2, tc2, boa, beta, c3, kvk, cv, hhd, hd, h6d;  // per chain (see Lane32)
-  float2v vref, hh, h, h6;                                   // the same value in both halves
-};
-
-__device__ __forceinline__ Lane32x2 make_lane32x2(const double dc[2], const double a[2], const double b[2], const Consts &K) {
-  const Lane32 A = make_lane32(dc[0], a[0], b[0], K), B = make_lane32(dc[1], a[1], b[1], K);
-  Lane32x2 L;
-  L.kia2 = float2v{A.kia2, B.kia2}; L.tc2 = float2v{A.tc2, B.tc2}; L.boa = float2v{A.boa, B.boa};
-  L.beta = float2v{A.beta, B.beta}; L.c3 = float2v{A.c3, B.c3}; L.kvk = float2v{A.kvk, B.kvk}; L.cv = float2v{A.cv, B.cv};
-  L.hhd = float2v{A.chh.y, B.chh.y}; L.hd = float2v{A.ch.y, B.ch.y}; L.h6d = float2v{A.ch6.y, B.ch6.y};
-  L.vref = float2v{A.vref, A.vref}; L.hh = float2v{A.chh.x, A.chh.x}; L.h = float2v{A.ch.x, A.ch.x}; L.h6 = float2v{A.ch6.x, A.ch6.x};
-  return L;
-}
-
-template <bool DAMP>
-__device__ __forceinline__ float2v rhs32x2(float2v ms, float2v x, float vl, const Lane32x2 &L, float2v &d0, float2v &d1) {
-#pragma clang fp contract(off)  // every fused multiply-add of this path is written out: one-chain and two-chain forms round alike
-  const float2v lg = {__builtin_amdgcn_logf(x.x), __builtin_amdgcn_logf(x.y)};
-  const float2v rx = {__builtin_amdgcn_rcpf(x.x), __builtin_amdgcn_rcpf(x.y)};
-  const float2v arg = pk_fma(-L.boa, lg, pk_fma(ms, L.kia2, L.tc2));
-  const float2v w = {__builtin_amdgcn_exp2f(arg.x), __builtin_amdgcn_exp2f(arg.y)};
-  const float2v vl2 = {vl, vl}, one = {1.0f, 1.0f};
-  const float2v t1 = pk_fma(-L.beta, rx, vl2);
-  d0 = pk_fma(-L.vref, w, vl2);
-  d1 = pk_fma(-w, x, one);
-  float2v g = pk_fma(L.c3, w, t1);
-  if (DAMP) {
-    const float2v kw = L.kvk * w;
-    d0 = pk_fma(-kw, g, d0);
-    g = pk_fma(-kw, g, g);
-  }
-  return w * g;
-}
-
-template <bool DAMP>
-__device__ __forceinline__ float2v rk4_step32x2(float2v &ms, float2v &x, float vl0, float vlm, float vl1, const Lane32x2 &L) {
-#pragma clang fp contract(off)  // every fused multiply-add of this path is written out: one-chain and two-chain forms round alike
-  float2v a0, a1, b0, b1, c0, c1, e0, e1;
-  const float2v wa = rhs32x2<DAMP>(ms, x, vl0, L, a0, a1);
-  const float2v wb = rhs32x2<DAMP>(pk_fma(L.hh, a0, ms), pk_fma(L.hhd, a1, x), vlm, L, b0, b1);
-  const float2v wc = rhs32x2<DAMP>(pk_fma(L.hh, b0, ms), pk_fma(L.hhd, b1, x), vlm, L, c0, c1);
-  const float2v we = rhs32x2<DAMP>(pk_fma(L.h, c0, ms), pk_fma(L.hd, c1, x), vl1, L, e0, e1);
-  const float2v two = {2.0f, 2.0f};
-  ms = pk_fma(L.h6, pk_fma(two, b0 + c0, a0 + e0), ms);
-  x = pk_fma(L.h6d, pk_fma(two, b1 + c1, a1 + e1), x);
-  return pk_fma(two, wb + wc, wa + we);
-}
-
-// sums of squares of two chains that share the observation series (both belong to the workgroup's group)
-template <bool DAMP>
-__device__ __forceinline__ void solve32x2(float *lds, const Consts &K, bool resident, const bool active[2], const double dc[2],
-                                          const double a[2], const double b[2], double ssq[2]) {
-#pragma clang fp contract(off)  // every fused multiply-add of this path is written out: one-chain and two-chain forms round alike
-  const Lane32x2 L = make_lane32x2(dc, a, b, K);
-  float2v ms = {(float)(K.mu0 / ((1e-2 * 10) / dc[0])), (float)(K.mu0 / ((1e-2 * 10) / dc[1]))}, x = {1.0f, 1.0f};
-  const bool any = active[0] || active[1];
-  ssq[0] = ssq[1] = 0.0;
-  if (any) {
-    const double d0 = (double)(float)K.data[0];
-    ssq[0] = ssq[1] = d0 * d0;
-  }
-  auto emit = [&](float2v dv, float obs) {
-    const float2v ak = dv * L.cv;  // RateStateModel.py:388, from the interval's velocity increment
-    const double r0 = (double)(ak.x - obs), r1 = (double)(ak.y - obs);
-    ssq[0] = __builtin_fma(r0, r0, ssq[0]);
-    ssq[1] = __builtin_fma(r1, r1, ssq[1]);
-  };
+  if (WANT_ACC && any) acc_out[0] = 0.0;
   for (int k0 = 1; k0 < K.nout; k0 += K.kc) {
     const int kn = min(K.kc, K.nout - k0);
     if (!resident) stage_chunk32(lds, K, k0, kn);
@@ -253,25 +478,36 @@ __device__ __forceinline__ void solve32x2(float *lds, const Consts &K, bool resi
     int kk = 0;
     if (K.S == 1) {
       constexpr int NU = 8;
-      for (; kk + NU <= kn; kk += NU) {
-        const float *v = lds + 2 * kk;
-        float obs[NU];
-        float2v dv[NU];
-#pragma unroll
-        for (int j = 0; j < NU; ++j) obs[j] = ld[kk + j];
-#pragma unroll
-        for (int j = 0; j < NU; ++j) dv[j] = rk4_step32x2<DAMP>(ms, x, v[2 * j], v[2 * j + 1], v[2 * j + 2], L);
-#pragma unroll
-        for (int j = 0; j < NU; ++j) emit(dv[j], obs[j]);
-      }
+      for (; kk + NU <= kn; kk += NU) trip32<DAMP, NU>(st, lds + 2 * kk, ld, k0 + kk, kk, L, out);
     }
     int j = 2 * K.S * kk;
     for (; kk < kn; ++kk) {
-      float2v dv = {0.0f, 0.0f};
-      for (int sub = 0; sub < K.S; ++sub, j += 2) dv += rk4_step32x2<DAMP>(ms, x, lds[j], lds[j + 1], lds[j + 2], L);
-      emit(dv, ld[kk]);
+      V dv = T::splat(0.0f);
+      for (int sub = 0; sub < K.S; ++sub, j += 2) dv += step_any<DAMP>(st, lds[j], lds[j + 1], lds[j + 2], L);
+      out.emit(k0 + kk, kk, ld, dv, true);
     }
   }
+#pragma unroll
+  for (int c = 0; c < N; ++c) ssq[c] = out.ssq[c];
+}
+
+// one chain per lane
+template <bool DAMP, bool WANT_SSQ, bool WANT_ACC>
+__device__ __forceinline__ double solve32(float *lds, const Consts &K, bool resident, bool active, double dc, double a,
+                                          double b, double *acc_out, int64_t stride) {
+  const bool act[1] = {active};
+  const double dcs[1] = {dc}, as[1] = {a}, bs[1] = {b};
+  double ssq[1];
+  solve32v<DAMP, WANT_SSQ, WANT_ACC, float>(lds, K, resident, act, dcs, as, bs, ssq, acc_out, stride);
+  return ssq[0];
+}
+
+// two chains per lane: sums of squares only.  ONLY for a kernel compiled with amdgpu_num_vgpr(RSF_F32_TRIP_COMPILER_VGPRS):
+// the assembly trip owns the registers above (trip32).
+template <bool DAMP>
+__device__ __forceinline__ void solve32x2(float *lds, const Consts &K, bool resident, const bool (&active)[2], const double (&dc)[2],
+                                          const double (&a)[2], const double (&b)[2], double (&ssq)[2]) {
+  solve32v<DAMP, true, false, float2v>(lds, K, resident, active, dc, a, b, ssq, nullptr, 0);
 }
 
 }  // namespace f32

@@ -757,7 +757,8 @@ struct Chain {
 };
 
 template <int D, bool DAMP, bool REPLAY>
-__global__ void __launch_bounds__(kMaxBlock, kMinBlocks) mcmc_f32x2_kernel(Consts K, McmcArgs A) {
+__global__ void __launch_bounds__(kMaxBlock, kMinBlocks) __attribute__((amdgpu_num_vgpr(RSF_F32_TRIP_COMPILER_VGPRS / 2)))
+mcmc_f32x2_kernel(Consts K, McmcArgs A) {  // (the registers above that count: the solve's private file, rsf_device_f32.h trip32)
   extern __shared__ __attribute__((aligned(16))) double lds[];
   constexpr int NC = 2;  // chains per lane
   // Per-chain arrays are addressed as (wave-uniform row pointer)[threadIdx.x]: the row pointer — array + element * C + the

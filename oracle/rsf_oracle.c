@@ -232,16 +232,25 @@ static void friction(const rsf_model *m, double t, double dc, double a, double b
 static double solve_dop853(const rsf_ctx *c, double dc, double a, double b, const double *data, double *acc, int64_t stride);
 
 /* RSF_FLAG_FP32_SOLVE (BASELINE config 5's float32 leg): the same fixed-step RK4 carried in IEEE float — plain `float`
- * arithmetic, exp2f / log2f, one rounding per operation (fmaf where the formula is a fused multiply-add).  It restates
- * the float32 FORMULATION of the product (csrc/rsf_device_f32.h), not an independent algorithm: the rescaled state
- * ms = mu/k', x = V_ref theta/Dc, the exponent pre-scaled to base 2, the acceleration sample from the step's velocity
- * increment (differencing two float velocities near V_ref would lose four digits), float tables, and a double sum of
- * squares of float residuals.  GPU and this restatement then differ only by the last-place behaviour of the hardware
- * v_exp_f32 / v_log_f32 / v_rcp_f32 against libm — which pins every constant and every term of the kernel far below
- * the 1e-3 band that separates float32 from float64 results. */
-typedef struct { float kia2, tc2, boa, beta, c3, kvk, vref, cv, hh, h, h6, hhd, hd, h6d; } lane32;
+ * arithmetic, one rounding per operation (fmaf where the formula is a fused multiply-add).  It restates the float32
+ * FORMULATION of the product (csrc/rsf_device_f32.h), not an independent algorithm: the rescaled state ms = mu/k',
+ * x = V_ref theta/Dc, the acceleration sample from the step's velocity increment (differencing two float velocities near
+ * V_ref would lose four digits), float tables, a double sum of squares of float residuals — and the product's rule for HOW a
+ * chain takes a step (round 4), which is a function of the chain's own parameters and trajectory only:
+ *   - incrementally (incr_step32): state (w, Rh = (h/2Dc)/x), every stage reached from the step's start by short series,
+ *     no transcendental function — while the step's END increments satisfy |rho| < 2^-10 and |dlt| < 2^-7 (NaN passes);
+ *   - from the first step that does not, to the end of the solve: full evaluations at every stage (full_step32: exp2f /
+ *     log2f / division where the GPU has v_exp_f32 / v_log_f32 / v_rcp_f32), starting from (ms, x = hhd/Rh) at that
+ *     step's start point.
+ * In the incremental form GPU and restatement execute the same IEEE operations in the same order: they agree bit for bit.
+ * In the full form they differ by the last-place behaviour of the hardware transcendentals against libm.  Either way every
+ * constant and every term of the kernel is pinned far below the 1e-3 band that separates float32 from float64 results. */
+typedef struct {
+  float kia2, tc2, boa, beta, c3, kvk, vref, cv, hh, h, h6, hhd, hd, h6d; /* full evaluation */
+  float khh, kh, kh6, nhboa, bh;                                         /* incremental step */
+} lane32;
 
-/* the RHS at (ms, x) in the product's regrouping (csrc/rsf_device_f32.h, rhs32): w = v/V_ref = 2^(kia2 ms + tc2 - (b/a) log2 x),
+/* the RHS at (ms, x) in the product's regrouping (csrc/rsf_device_f32.h, rhs_full): w = v/V_ref = 2^(kia2 ms + tc2 - (b/a) log2 x),
  * d(ms)/dt = V_l - V_ref w, dtheta/dt = 1 - w x, and dV/dt = vk w g with g = (V_l - beta/x) + (beta - V_ref) w; the damping
  * pass (RateStateModel.py:349-353) subtracts (kvk w) g from d(ms)/dt and from g.  Returns w g. */
 static float rhs32(const lane32 *L, int damp, float ms, float x, float vl, float *d0, float *d1) {
@@ -260,19 +269,89 @@ static float rhs32(const lane32 *L, int damp, float ms, float x, float vl, float
   return w * g;
 }
 
+/* one RK4 step by full evaluations (csrc/rsf_device_f32.h, rk4_full); returns k1 + 2 k2 + 2 k3 + k4 of dV/dt in units of vk */
+static float full_step32(const lane32 *L, int damp, float *ms_io, float *x_io, float vl0, float vlm, float vl1) {
+  float ms = *ms_io, x = *x_io, a0, a1, b0, b1, c0, c1, e0, e1;
+  float wa = rhs32(L, damp, ms, x, vl0, &a0, &a1);
+  float wb = rhs32(L, damp, fmaf(L->hh, a0, ms), fmaf(L->hhd, a1, x), vlm, &b0, &b1);
+  float wc = rhs32(L, damp, fmaf(L->hh, b0, ms), fmaf(L->hhd, b1, x), vlm, &c0, &c1);
+  float we = rhs32(L, damp, fmaf(L->h, c0, ms), fmaf(L->hd, c1, x), vl1, &e0, &e1);
+  *ms_io = fmaf(L->h6, fmaf(2.0f, b0 + c0, a0 + e0), ms);
+  *x_io = fmaf(L->h6d, fmaf(2.0f, b1 + c1, a1 + e1), x);
+  return fmaf(2.0f, wb + wc, wa + we);
+}
+
+/* the RHS of the incremental form (csrc/rsf_device_f32.h, rhs_incr): theta derivatives scaled by Rh,
+ * d1' = Rh (1 - w x) = Rh - w xr with xr = Rh x at the stage; d0 = V_l - V_ref w; g = d0 - brx d1' (+ the damping pass) */
+static void rhs_incr32(const lane32 *L, int damp, float w, float xr, float Rh, float vl, float brx, float *d0, float *d1, float *g) {
+  float e1 = fmaf(-w, xr, Rh);
+  float e0 = fmaf(-L->vref, w, vl);
+  float gg = fmaf(-brx, e1, e0);
+  if (damp) {
+    float kw = L->kvk * w;
+    e0 = fmaf(-kw, gg, e0);
+    gg = fmaf(-kw, gg, gg);
+  }
+  *d0 = e0; *d1 = e1; *g = gg;
+}
+
+/* (w', q) at the point reached from the step's start (w0, x) by rho = dx/x and d(mu)/a = kd d0 (csrc/rsf_device_f32.h, incr, in
+ * its operation order): dlt = kd d0 - (b/a) log1p(rho) to rho^2/2, w' = w0 exp(dlt) to dlt^3/6 as
+ * w0 (1 + dlt) + dlt^2 (w0/2 + (w0/6) dlt), 1/x' = (1/x)(1 + q) with q = -rho + rho^2 */
+static void incr32(const lane32 *L, float rho, float kd, float d0, float w0, float w02, float w06, float *w, float *q, float *dlt_out) {
+  float rP = rho * fmaf(rho, L->nhboa, L->boa);
+  float dlt = fmaf(kd, d0, -rP);
+  float d2 = dlt * dlt, A = fmaf(dlt, w0, w0), B = fmaf(dlt, w06, w02);
+  *w = fmaf(d2, B, A);
+  *q = fmaf(rho, rho, -rho);
+  *dlt_out = dlt;
+}
+
+/* one RK4 step of the incremental form (csrc/rsf_device_f32.h, rk4_incr) */
+static float incr_step32(const lane32 *L, int damp, float *w_io, float *Rh_io, float *ms_io, float vl0, float vlm, float vl1,
+                         float *rho_end, float *dlt_end) {
+  const float w0 = *w_io, Rh = *Rh_io, third = 1.0f / 3.0f;
+  const float w02 = w0 * 0.5f, w06 = w0 * (1.0f / 6.0f);
+  float a0, a1, ga, b0, b1, gb, c0, c1, gc, e0, e1, ge, w, q, dlt;
+  rhs_incr32(L, damp, w0, L->hhd, Rh, vl0, L->bh, &a0, &a1, &ga);
+  float sv = w0 * ga;
+  incr32(L, a1, L->khh, a0, w0, w02, w06, &w, &q, &dlt);
+  rhs_incr32(L, damp, w, fmaf(L->hhd, a1, L->hhd), Rh, vlm, fmaf(L->bh, q, L->bh), &b0, &b1, &gb);
+  float sm = w * gb;
+  incr32(L, b1, L->khh, b0, w0, w02, w06, &w, &q, &dlt);
+  rhs_incr32(L, damp, w, fmaf(L->hhd, b1, L->hhd), Rh, vlm, fmaf(L->bh, q, L->bh), &c0, &c1, &gc);
+  sm = fmaf(w, gc, sm);
+  const float T0 = fmaf(2.0f, b0 + c0, a0), T13 = fmaf(2.0f, b1 + c1, a1) * third;
+  incr32(L, c1 + c1, L->kh, c0, w0, w02, w06, &w, &q, &dlt);
+  rhs_incr32(L, damp, w, fmaf(L->hd, c1, L->hhd), Rh, vl1, fmaf(L->bh, q, L->bh), &e0, &e1, &ge);
+  sv = fmaf(w, ge, sv);
+  const float t0 = T0 + e0;
+  *rho_end = fmaf(e1, third, T13);
+  incr32(L, *rho_end, L->kh6, t0, w0, w02, w06, &w, &q, dlt_end);
+  *ms_io = fmaf(L->h6, t0, *ms_io);
+  *w_io = w;
+  *Rh_io = fmaf(Rh, q, Rh);
+  return fmaf(2.0f, sm, sv);
+}
+
 static double solve_f32(const rsf_ctx *c, double dc, double a, double b, const double *data, double *acc, int64_t stride) {
   const rsf_model *m = &c->m;
   const int S = m->substeps, damp = (m->flags & RSF_FLAG_RADIATION_DAMPING) != 0;
   const double h = c->h, hh = 0.5 * c->h, h6 = c->h / 6.0, log2e = 1.4426950408889634074;
   const double inv_a = 1.0 / a, inv_dc = 1.0 / dc, kprime = (1e-2 * 10) / dc, vdc = m->V_ref * inv_dc;
+  const double beta = b * m->V_ref * (1.0 / (1e-2 * 10));
   lane32 L;
   L.kia2 = (float)(kprime * inv_a * log2e); L.tc2 = (float)(-m->mu_ref * inv_a * log2e); L.boa = (float)(b * inv_a);
-  L.beta = (float)(b * m->V_ref * (1.0 / (1e-2 * 10))); L.c3 = (float)(b * m->V_ref * (1.0 / (1e-2 * 10)) - m->V_ref);
+  L.beta = (float)beta; L.c3 = (float)(beta - m->V_ref);
   L.kvk = (float)(m->k1 * m->V_ref * inv_a); L.vref = (float)m->V_ref;
   L.cv = (float)((h6 * (1.0 / c->delta_t)) * (m->V_ref * inv_a * kprime));
   L.hh = (float)hh; L.h = (float)h; L.h6 = (float)h6;
   L.hhd = (float)(hh * vdc); L.hd = (float)(h * vdc); L.h6d = (float)(h6 * vdc);
-  float ms = (float)(m->mu_t_zero / kprime), x = 1.0f;
+  L.khh = (float)(kprime * inv_a * hh); L.kh = (float)(kprime * inv_a * h); L.kh6 = (float)(kprime * inv_a * h6);
+  L.nhboa = (float)(-0.5 * (b * inv_a)); L.bh = (float)(beta / (hh * vdc));
+  /* x(0) = 1: w(0) = exp((mu(0) - mu_ref)/a), evaluated in double and rounded once; Rh(0) = hhd */
+  float ms = (float)(m->mu_t_zero / kprime), x = 1.0f, w = (float)exp((m->mu_t_zero - m->mu_ref) * inv_a), Rh = L.hhd;
+  int full = 0;
   double ssq = 0.0;
   int64_t j = 0;
   if (acc) acc[0] = 0.0;
@@ -285,15 +364,15 @@ static double solve_f32(const rsf_ctx *c, double dc, double a, double b, const d
       float vl0 = (float)(m->V_ref * (1 + exp(-t0 / 20) * sin(10 * t0)));
       float vlm = (float)(m->V_ref * (1 + exp(-tm / 20) * sin(10 * tm)));
       float vl1 = (float)(m->V_ref * (1 + exp(-t1 / 20) * sin(10 * t1)));
-      float a0, a1, b0, b1, c0, c1, e0, e1;
-      float wa = rhs32(&L, damp, ms, x, vl0, &a0, &a1);
-      float wb = rhs32(&L, damp, fmaf(L.hh, a0, ms), fmaf(L.hhd, a1, x), vlm, &b0, &b1);
-      float wc = rhs32(&L, damp, fmaf(L.hh, b0, ms), fmaf(L.hhd, b1, x), vlm, &c0, &c1);
-      float we = rhs32(&L, damp, fmaf(L.h, c0, ms), fmaf(L.hd, c1, x), vl1, &e0, &e1);
-      ms = fmaf(L.h6, fmaf(2.0f, b0 + c0, a0 + e0), ms);
-      x = fmaf(L.h6d, fmaf(2.0f, b1 + c1, a1 + e1), x);
-      float wsum = fmaf(2.0f, wb + wc, wa + we);
-      dv = S == 1 ? wsum : dv + wsum;
+      float wsum = 0.0f;
+      if (!full) {
+        float w1 = w, Rh1 = Rh, ms1 = ms, rho, dlt;
+        wsum = incr_step32(&L, damp, &w1, &Rh1, &ms1, vl0, vlm, vl1, &rho, &dlt);
+        if (!(fabsf(rho) >= 0x1p-10f) && !(fabsf(dlt) >= 0x1p-7f)) { w = w1; Rh = Rh1; ms = ms1; }
+        else { x = (float)((double)L.hhd / (double)Rh); full = 1; }  /* this step and every later one by full evaluations */
+      }
+      if (full) wsum = full_step32(&L, damp, &ms, &x, vl0, vlm, vl1);
+      dv = dv + wsum;
     }
     float ak = dv * L.cv;                                                /* RateStateModel.py:388, from the increment */
     if (acc) acc[k * stride] = (double)ak;

@@ -168,3 +168,14 @@ def test_engine_refuses_the_checker_library_unless_declared(pkg, oracle_lib, mon
         pkg.Engine(lib=oracle_lib)
     monkeypatch.setenv("RSF_ALLOW_CHECKER_ENGINE", "1")
     pkg.Engine(lib=oracle_lib).close()
+
+
+def test_generated_trip_is_current():
+    """csrc/rsf_f32_trip.inc (the float32 sampler's scheduled-assembly trip) is what tools/gen_f32_trip.py generates."""
+    import subprocess
+    import sys
+
+    from conftest import ROOT
+
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_f32_trip.py"), "--check"], capture_output=True, text=True)
+    assert out.returncode == 0 and out.stdout.strip() == "ok", out.stdout + out.stderr

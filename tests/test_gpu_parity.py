@@ -935,6 +935,70 @@ def test_float32_sampler_two_chains_per_lane(pkg, oracle_lib, oracle_mod, d, C, 
     np.testing.assert_allclose(tg[1][:, same], tc[1][:, same], rtol=1e-6)
 
 
+def test_float32_step_forms_mixed_in_one_wave(pkg, oracle_lib, oracle_mod):
+    """The float32 solve's two step forms (csrc/rsf_device_f32.h): a chain integrates incrementally — no transcendental
+    function; in the sampler as scheduled assembly over a private register file (rsf_f32_trip.inc) — until one of its own
+    steps leaves the guard, and by full evaluations from that step on.  Chains of every kind side by side: Dc from 8 (full
+    evaluations from the first step) over 60 and 130 (switching somewhere along the series, as the loading's amplitude has
+    it) to 3000, in a 7-cycle over the chain index, so that every wave holds all kinds and the two chains of a lane differ
+    (replayed trips, waves running both forms).
+    (a) one-chain forward kernel (compiled C++) against the restatement: where the chain stays incremental the two execute
+        the same IEEE operations — trajectories and SSq BIT-identical; elsewhere the hardware transcendentals' last place
+        shows (5e-7 / 5e-6 as in test_float32_solve_against_the_float32_restatement for Dc >= 100; the stiff kinds below, where
+        no earlier test went, amplify it: 5e-5 / 5e-4, measured 3e-6 on SSq);
+    (b) the sampler (assembly trip, two chains per lane): the SSq it holds for a chain's point is bit-identical to the
+        one-chain forward kernel's at that point, for every kind of chain;
+    (c) the sampler's chains against the restatement run as a sampler: same decisions in >= 99 % of the chains."""
+    n, C = 500, 1792
+    m = _models(oracle_mod, n)
+    m.precision = "float32"
+    kinds = np.array([8.0, 1200.0, 60.0, 3000.0, 130.0, 500.0, 25.0])
+    rng = np.random.default_rng(21)
+    dc0 = kinds[np.arange(C) % 7] * rng.uniform(0.9, 1.1, C)
+    with pkg.Engine(mem="host") as g, pkg.Engine(lib=oracle_lib) as c, pkg.Engine(lib=oracle_lib) as c64:
+        for e in (g, c):
+            e.set_model(m, 1)
+        c64.set_model(_models(oracle_mod, n), 1)
+        data = synthetic_data(c64)
+        # (a)
+        sg, ag = g.forward(dc0, data=data, want_ssq=True, want_acc=True)
+        sc, ac = c.forward(dc0, data=data, want_ssq=True, want_acc=True)
+        sg, ag, sc, ac = np.asarray(sg), np.asarray(ag), np.asarray(sc), np.asarray(ac)
+        calm = dc0 > 400.0                        # a-priori incremental throughout at this step size (|dlt| < 2^-7 needs Dc a > 1.3)
+        exact = (ag == ac).all(axis=0) & (sg == sc)
+        print(f"float32 forward, GPU vs restatement: {int(exact.sum())} of {C} chains bit-identical ({int(exact[calm].sum())} of {int(calm.sum())} with Dc > 400)")
+        assert exact[calm].all()
+        assert not exact[dc0 < 30.0].all()        # the full-evaluation form really runs: its last place differs somewhere
+        fin = np.isfinite(sc)
+        assert (np.isfinite(sg) == fin).all() and fin.sum() > 0.8 * C
+        e_ssq, e_traj = np.abs(sg / sc - 1), np.abs(ag - ac).max(axis=0) / np.abs(ac).max(axis=0)
+        stiff = dc0 < 100.0  # full evaluations from early on, and a stiff problem: the transcendentals' last place is amplified
+        print("  per kind (Dc: SSq, trajectory): " + "; ".join(
+            f"{kd:g}: {e_ssq[fin & (np.abs(dc0 / kd - 1) < 0.11)].max():.1e}, {e_traj[fin & (np.abs(dc0 / kd - 1) < 0.11)].max():.1e}" for kd in kinds))
+        assert e_ssq[fin & ~stiff].max() < 5e-7 and e_traj[fin & ~stiff].max() < 5e-6
+        assert e_ssq[fin & stiff].max() < 5e-5 and e_traj[fin & stiff].max() < 5e-4
+        # (b), (c)
+        q0 = dc0[:, None]
+        for e in (g, c):
+            e.mcmc_init(q0, data, [0.0], [1.0e4], seed=5, prior_len=3, adapt_mode="none")
+        state0 = list(c.get_state())
+        state0[3] = ((0.02 * dc0) ** 2)[:, None, None]
+        for e in (g, c):
+            e.set_state(*state0)
+        tg, tc = g.mcmc_run(10), c.mcmc_run(10)
+        q, ssq, _, _ = g.get_state()
+        f, _ = g.forward(q[:, 0], data=data, want_ssq=True, want_acc=False)
+        moved = tg[2].any(axis=0)
+        for kd in kinds:
+            sel = moved & (np.abs(dc0 / kd - 1) < 0.11)
+            assert sel.sum() > 20, (kd, int(sel.sum()))
+            np.testing.assert_array_equal(ssq[sel], f[sel])
+    same = (tg[2] == tc[2]).all(axis=0)
+    print(f"float32 sampler, mixed forms, vs restatement: {int((~same).sum())} of {C} chains differ in a decision")
+    assert same.mean() >= 0.99
+    np.testing.assert_allclose(tg[0][:, same], tc[0][:, same], rtol=1e-9)
+
+
 def test_float32_sampler_is_exact_at_config5_shape(pkg, oracle_mod):
     """The packed two-chains-per-lane solve at BASELINE configs[4]'s own per-GPU shape (131 072 chains, nsteps 4000, joint
     (Dc, a, b): two LDS chunks per solve): after three proposals every chain's SSq is bit-identical to the one-chain float32

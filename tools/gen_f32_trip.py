@@ -1,0 +1,374 @@
+#!/usr/bin/env python3
+"""
+Generates csrc/rsf_f32_trip.inc: the float32 sampler's incremental TRIP — eight RK4 steps of rsf::f32::rk4_incr
+(rsf_device_f32.h) for the lane's two chains, with the emission of their samples and the trip's guard sums — as
+hand-scheduled gfx950 assembly: one asm statement per variant (with / without radiation damping).
+
+Why.  Config 5's shape is one wave per SIMD: the wave is bound by its own instruction issue, 4 cycles per vector
+instruction (tools/microbench_issue.hip, profiles/r04/microbench_issue.log: 4.06 independent, 5.05 when the instruction reads
+the result of the one before it, and 8.05 per pair with the `s_nop 0` that hipcc puts between such a pair — its hazard
+recogniser takes op_sel_hi of source 0, set on every packed-f32 instruction, for a destination op_sel; the hardware needs no
+wait state there: tools/microbench_pk_f32.hip computes bit-identical results without).  An RK4 step is one long dependency
+chain of ~90 operations.  Left to hipcc it became 79 packed operations + 16 emission and guard operations + ~16 wait states
+per step, ordered for register pressure (534 cycles per step measured; -misched=gcn-max-ilp does worse, gcn-iterative-ilp
+crashes the compiler); statement order is not honoured, a scheduler barrier does not stop IR-level sinking, and an empty-asm
+pin on a result draws a wait state itself.  So the trip is written here: the dataflow, an order of issue in which an
+instruction rarely follows its own producer (list scheduling of the whole trip, one step's tail under the next step's head),
+a register allocation, and the instructions — 88 per step, no wait states.
+
+Registers.  The sampler kernel is compiled with amdgpu_num_vgpr(kCompilerVgprs): the compiler allocates below that and never
+touches what lies above — the solve's PRIVATE FILE, v[PRIV0 .. 255].  It holds the per-chain constants (parked once per solve
+by the setup statement this script also prints), the trip's table values and its temporaries.  The chain state (w, Rh, ms),
+the sums of squares and the guard sums are ordinary in/out operands, so the C++ around the trip keeps the trip's start
+values for the rare replay.
+
+The dataflow is rk4_incr's, operation for operation and operand for operand (the generic C++ function remains the
+definition: step_any runs it wherever a trip is replayed step by step and in the one-chain form, and oracle/rsf_oracle.c
+restates it), so a chain's values do not depend on which of the two ran — tested bit for bit (GPU trip against the
+restatement; the two-chain sampler against the one-chain forward kernel).
+
+  python tools/gen_f32_trip.py            writes the file, prints the model's cycle counts and the register budget
+  python tools/gen_f32_trip.py --check    verifies the committed file is what this script produces
+"""
+import argparse
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OUT = os.path.join(ROOT, "bayesian-markov-chain-monte-carlo_amd", "csrc", "rsf_f32_trip.inc")
+
+NU = 8
+ISSUE = 4                              # cycles between two issues of one wave
+# Spacing the list scheduler aims for between an instruction and the first reader of its result, by kind (packed float /
+# scalar float / float64).  Not measured latencies: a reader directly behind its producer costs one cycle (header), and with
+# these targets the scheduler keeps them apart wherever the dataflow offers something else to issue.
+LAT = {"pk": 10, "f": 6, "d": 8}
+COMPILER_VGPRS = 160                   # amdgpu_num_vgpr of the sampler kernel; the private file is v[160:255]
+PRIV0 = COMPILER_VGPRS
+CONSTS = ["hhd", "hd", "khh", "kh", "kh6", "boa", "nhboa", "kvk", "bh", "cv", "vref", "h6", "c16", "c13"]
+# in/out operands of the trip statement, in this order; then the two LDS byte addresses
+OPERANDS = ["w", "Rh", "ms", "q0", "q1", "g2r", "g2d"]
+ADDR_VV, ADDR_OB = len(OPERANDS), len(OPERANDS) + 1
+
+
+class Src:
+    def __init__(self, kind, val, neg=False):
+        self.kind, self.val, self.neg = kind, val, neg   # kind: t (value by name) | c (constant) | vl (table index) | imm
+
+
+def T(name, neg=False): return Src("t", name, neg)
+def C(name, neg=False): return Src("c", name, neg)
+def VL(i): return Src("vl", i)
+def IMM(text): return Src("imm", text)
+
+
+class Op:
+    def __init__(self, name, kind, opcode, srcs, step, dest_fixed=None):
+        self.name, self.kind, self.opcode, self.srcs, self.step, self.dest_fixed = name, kind, opcode, srcs, step, dest_fixed
+        self.users, self.prio, self.t_issue = [], 0, None
+
+    def deps(self):
+        return [s.val for s in self.srcs if s.kind == "t"]
+
+
+def build(damp):
+    ops, by = [], {}
+
+    def op(name, kind, opcode, srcs, step, dest_fixed=None):
+        o = Op(name, kind, opcode, srcs, step, dest_fixed)
+        ops.append(o)
+        by[name] = o
+        return name
+
+    w, Rh, ms = "w", "Rh", "ms"            # operand names: the state at the trip's start
+    q = ["q0", "q1"]
+    g2r = g2d = None
+    for j in range(NU):
+        s = f"_{j}"
+
+        def fma(n, a, b, c): return op(n + s, "pk", "fma", [a, b, c], j)
+        def mul(n, a, b): return op(n + s, "pk", "mul", [a, b], j)
+        def add(n, a, b): return op(n + s, "pk", "add", [a, b], j)
+
+        def rhs(tag, wv, xr, brx, vl):
+            d1 = fma(tag + "1", T(wv, True), xr, T(Rh))                  # d1' = Rh - w xr
+            d0r = fma(tag + "0r", C("vref", True), T(wv), VL(vl))         # V_l - V_ref w
+            gr = fma("g" + tag + "r", Src(brx.kind, brx.val, True), T(d1), T(d0r))
+            if not damp:
+                return d0r, d1, gr
+            kw = mul("kw" + tag, C("kvk"), T(wv))
+            d0 = fma(tag + "0", T(kw, True), T(gr), T(d0r))
+            g = fma("g" + tag, T(kw, True), T(gr), T(gr))
+            return d0, d1, g
+
+        def incr(tag, rho, kd, d0):
+            P = fma("P" + tag, T(rho), C("nhboa"), C("boa"))
+            rP = mul("rP" + tag, T(rho), T(P))
+            dl = fma("dl" + tag, C(kd), T(d0), T(rP, True))
+            d2 = mul("d2" + tag, T(dl), T(dl))
+            A = fma("A" + tag, T(dl), T(w), T(w))
+            B = fma("B" + tag, T(dl), T("w06" + s), T("w02" + s))
+            wn = fma("w" + tag, T(d2), T(B), T(A))
+            qn = fma("q" + tag, T(rho), T(rho), T(rho, True))
+            return wn, qn, dl
+
+        mul("w02", T(w), IMM("0.5"))
+        mul("w06", T(w), C("c16"))
+        a0, a1, ga = rhs("a", w, C("hhd"), C("bh"), 2 * j)
+        sv = mul("sv1", T(w), T(ga))
+        wb, qa, _ = incr("a", a1, "khh", a0)
+        xrb = fma("xrb", C("hhd"), T(a1), C("hhd"))
+        brb = fma("brb", C("bh"), T(qa), C("bh"))
+        b0, b1, gb = rhs("b", wb, T(xrb), T(brb), 2 * j + 1)
+        sm = mul("sm1", T(wb), T(gb))
+        wc, qb, _ = incr("b", b1, "khh", b0)
+        xrc = fma("xrc", C("hhd"), T(b1), C("hhd"))
+        brc = fma("brc", C("bh"), T(qb), C("bh"))
+        c0, c1, gc = rhs("c", wc, T(xrc), T(brc), 2 * j + 1)
+        sm = fma("sm2", T(wc), T(gc), T(sm))
+        bc0 = add("bc0", T(b0), T(c0))
+        T0 = fma("T0", IMM("2.0"), T(bc0), T(a0))
+        bc1 = add("bc1", T(b1), T(c1))
+        T1 = fma("T1", IMM("2.0"), T(bc1), T(a1))
+        T13 = mul("T13", T(T1), C("c13"))
+        rc = add("rc", T(c1), T(c1))
+        we, qc, _ = incr("c", rc, "kh", c0)
+        xre = fma("xre", C("hd"), T(c1), C("hhd"))
+        bre = fma("bre", C("bh"), T(qc), C("bh"))
+        e0, e1, ge = rhs("e", we, T(xre), T(bre), 2 * j + 2)
+        sv = fma("sv2", T(we), T(ge), T(sv))
+        t0 = add("t0", T(T0), T(e0))
+        rhoE = fma("rhoE", T(e1), C("c13"), T(T13))
+        wn, qn, dlE = incr("n", rhoE, "kh6", t0)
+        msn = fma("msn", C("h6"), T(t0), T(ms))
+        Rhn = fma("Rhn", T(Rh), T(qn), T(Rh))
+        dv = fma("dv", IMM("2.0"), T(sm), T(sv))
+        # the trip's guard sums, accumulated in place in their operands
+        if g2r is None:
+            g2r = op("g2r" + s, "pk", "mul", [T(rhoE), T(rhoE)], j, dest_fixed="g2r")
+            g2d = op("g2d" + s, "pk", "mul", [T(dlE), T(dlE)], j, dest_fixed="g2d")
+        else:
+            g2r = op("g2r" + s, "pk", "fma", [T(rhoE), T(rhoE), T(g2r)], j, dest_fixed="g2r")
+            g2d = op("g2d" + s, "pk", "fma", [T(dlE), T(dlE), T(g2d)], j, dest_fixed="g2d")
+        ak = mul("ak", T(dv), C("cv"))        # RateStateModel.py:388, from the interval's velocity increment
+        for c in range(2):
+            rs = op(f"rs{c}{s}", "f", "sub", [Src("half", (ak, c)), Src("ob", j)], j)
+            rd = op(f"rd{c}{s}", "d", "cvt", [T(rs)], j)
+            q[c] = op(f"q{c}{s}", "d", "fma64", [T(rd), T(rd), T(q[c])], j, dest_fixed=f"q{c}")
+        w, Rh, ms = wn, Rhn, msn
+    final = {"w": w, "Rh": Rh, "ms": ms}
+    return ops, by, final
+
+
+def op_deps(o):
+    d = o.deps()
+    for s in o.srcs:
+        if s.kind == "half":
+            d.append(s.val[0])
+    return d
+
+
+def schedule(ops, by):
+    for o in ops:
+        for s in op_deps(o):
+            if s in by:
+                by[s].users.append(o)
+    for o in reversed(ops):      # priority: the longest latency-weighted path to the end of the trip
+        o.prio = LAT[o.kind] + max((u.prio for u in o.users), default=0)
+    ready_at, order, t, done, left = {}, [], 0, set(), list(ops)
+    while left:
+        cur = min(o.step for o in left)
+        cands = [o for o in left if o.step <= cur + 1 and all((s not in by) or (s in done) for s in op_deps(o))]
+        avail = [(max([ready_at.get(s, 0) for s in op_deps(o)], default=0), o) for o in cands]
+        now = [(r, o) for r, o in avail if r <= t]
+        if now:
+            pick = max(now, key=lambda ro: (ro[1].prio, -ro[1].step))[1]
+        else:                    # nothing is ready: the wave waits for the earliest result
+            pick = min(avail, key=lambda ro: (ro[0], -ro[1].prio))[1]
+            t = max(ready_at.get(s, 0) for s in op_deps(pick))
+        pick.t_issue = t
+        ready_at[pick.name] = t + LAT[pick.kind]
+        done.add(pick.name)
+        left.remove(pick)
+        order.append(pick)
+        t += ISSUE
+    return order, t
+
+
+class Regs:
+    """Private file layout: constants, tables, then a pool of pairs for temporaries (linear scan over the schedule)."""
+
+    def __init__(self):
+        r = PRIV0
+        self.const = {}
+        for c in CONSTS:
+            self.const[c] = r
+            r += 2
+        self.vv = r          # 2 NU + 1 floats, base aligned to 4 registers for ds_read_b128
+        assert self.vv % 4 == 0, "table base must be aligned for ds_read_b128"
+        r += 2 * NU + 2
+        self.ob = r          # NU floats
+        r += NU
+        self.pool = list(range(r, 256, 2))
+        self.max_used = 0
+        self.n_pool = len(self.pool)
+
+    def alloc(self):
+        if not self.pool:
+            sys.exit("private register file exhausted: lower the scheduling window or raise the file")
+        p = self.pool.pop(0)
+        self.max_used = max(self.max_used, self.n_pool - len(self.pool))
+        return p
+
+    def free(self, p):
+        self.pool.insert(0, p)   # reuse the most recently freed pair first keeps the footprint small
+
+
+def pair(r): return f"v[{r}:{r + 1}]"
+
+
+def emit_asm(order, by, final, regs):
+    last_use = {}
+    for i, o in enumerate(order):
+        for s in op_deps(o):
+            last_use[s] = i
+    for v in final.values():
+        last_use[v] = len(order)
+    where = {name: f"%{i}" for i, name in enumerate(OPERANDS)}     # operands print as %N (register pairs)
+    phys = {}
+    lines = []
+    for i, o in enumerate(order):
+        # destination
+        if o.dest_fixed:
+            dst = where[o.dest_fixed]
+        else:
+            phys[o.name] = regs.alloc()
+            dst = pair(phys[o.name]) if o.kind != "f" else f"v{phys[o.name]}"
+
+        def loc(name):
+            if name in phys:
+                return pair(phys[name])
+            if name in where:
+                return where[name]
+            fixed = by[name].dest_fixed
+            return where[fixed]
+
+        if o.kind == "pk":
+            n = len(o.srcs)
+            txt, sel, selhi, neg = [], [0] * n, [1] * n, [0] * n
+            for k, s in enumerate(o.srcs):
+                if s.kind == "t":
+                    txt.append(loc(s.val))
+                elif s.kind == "c":
+                    txt.append(pair(regs.const[s.val]))
+                elif s.kind == "vl":          # one float of the table, for both chains: the register pair that holds it, one half
+                    r = regs.vv + s.val
+                    txt.append(pair(r & ~1))
+                    sel[k], selhi[k] = r & 1, r & 1
+                elif s.kind == "imm":
+                    txt.append(s.val)
+                    selhi[k] = 0
+                neg[k] = 1 if s.neg else 0
+            mods = ""
+            if any(sel):
+                mods += " op_sel:[" + ",".join(map(str, sel)) + "]"
+            if not all(selhi):
+                mods += " op_sel_hi:[" + ",".join(map(str, selhi)) + "]"
+            if any(neg):
+                mods += " neg_lo:[" + ",".join(map(str, neg)) + "] neg_hi:[" + ",".join(map(str, neg)) + "]"
+            ins = f"v_pk_{o.opcode}_f32 {dst}, " + ", ".join(txt) + mods
+        elif o.opcode == "sub":                # residual of one chain: its half of ak minus the observation
+            (akname, c), j = o.srcs[0].val, o.srcs[1].val
+            ins = f"v_sub_f32_e32 {dst}, v{phys[akname] + c}, v{regs.ob + j}"
+        elif o.opcode == "cvt":
+            ins = f"v_cvt_f64_f32_e32 {dst}, v{phys[o.srcs[0].val]}"
+        elif o.opcode == "fma64":
+            r = loc(o.srcs[0].val)
+            ins = f"v_fma_f64 {dst}, {r}, {r}, {dst}"
+        lines.append(ins)
+        # registers whose value is dead after this instruction
+        for s in dict.fromkeys(op_deps(o)):   # (in order: the register assignment must not depend on hash seeds)
+            if last_use.get(s) == i and s in phys:
+                regs.free(phys.pop(s))
+        if o.name not in last_use and o.name in phys:      # a result nobody reads (none expected)
+            regs.free(phys.pop(o.name))
+    for k, v in final.items():
+        lines.append(f"v_pk_mov_b32 {where[k]}, {pair(phys[v])}, {pair(phys[v])} op_sel:[0,1]")
+    return lines
+
+
+def loads(regs):
+    out = []
+    for i in range(0, 2 * NU, 4):
+        out.append(f"ds_read_b128 v[{regs.vv + i}:{regs.vv + i + 3}], %{ADDR_VV}" + (f" offset:{4 * i}" if i else ""))
+    out.append(f"ds_read_b32 v{regs.vv + 2 * NU}, %{ADDR_VV} offset:{8 * NU}")
+    for j in range(0, NU, 2):
+        out.append(f"ds_read2_b32 v[{regs.ob + j}:{regs.ob + j + 1}], %{ADDR_OB} offset0:{j} offset1:{j + 1}")
+    out.append("s_waitcnt lgkmcnt(0)")
+    return out
+
+
+def c_string(lines, indent="      "):
+    return "\n".join(f'{indent}"{l}\\n\\t"' for l in lines)
+
+
+def generate():
+    out = []
+    out.append("// GENERATED by tools/gen_f32_trip.py — do not edit; `python tools/gen_f32_trip.py --check` verifies it.")
+    out.append("// The float32 sampler's incremental trip (rsf::f32::trip32, two chains per lane) as hand-scheduled gfx950 assembly, and")
+    out.append("// the statement that parks the solve's constants in the private register file.  Why and how: that script's header.")
+    regs0 = Regs()
+    out.append(f"#define RSF_F32_TRIP_COMPILER_VGPRS {COMPILER_VGPRS}")
+    out.append(f"#define RSF_F32_TRIP_STEPS {NU}")
+    out.append("")
+    out.append("// per-chain constants of the solve → the private file (once per solve); the literals 1/6 and 1/3 are written there too")
+    setup = []
+    names = [c for c in CONSTS if c not in ("c16", "c13")]
+    for i, c in enumerate(names):
+        r = regs0.const[c]
+        setup.append(f"v_pk_mov_b32 {pair(r)}, %{i}, %{i} op_sel:[0,1]")
+    for c, bits in (("c16", "0x3e2aaaab"), ("c13", "0x3eaaaaab")):
+        r = regs0.const[c]
+        setup.append(f"v_mov_b32_e32 v{r}, {bits}")
+        setup.append(f"v_mov_b32_e32 v{r + 1}, {bits}")
+    out.append("#define RSF_F32_TRIP_SETUP(L) \\")
+    out.append("  asm volatile( \\")
+    out.append("\n".join(f'      "{l}\\n\\t" \\' for l in setup))
+    out.append("      : : " + ", ".join(f'"v"((L).{c})' for c in names) + ' : "v255")')
+    out.append("")
+    report = []
+    for damp in (True, False):
+        ops, by, final = build(damp)
+        order, cycles = schedule(ops, by)
+        regs = Regs()
+        body = loads(regs) + emit_asm(order, by, final, regs)
+        npk = sum(o.kind == "pk" for o in ops)
+        tag = "DAMPED" if damp else "UNDAMPED"
+        report.append(f"{tag.lower()}: {len(ops)} operations ({npk} packed), model {cycles} cycles = {cycles / NU:.0f} per step; private file: "
+                      f"{2 * len(CONSTS)} constants + {2 * NU + 2 + NU} table + {2 * regs.max_used} of {2 * regs.n_pool} temporaries")
+        out.append(f"// {report[-1]}")
+        out.append(f"#define RSF_F32_TRIP_{tag}(w, Rh, ms, q0, q1, g2r, g2d, vv_addr, ob_addr) \\")
+        out.append("  asm volatile( \\")
+        out.append("\n".join(f'      "{l}\\n\\t" \\' for l in body))
+        out.append('      : "+v"(w), "+v"(Rh), "+v"(ms), "+v"(q0), "+v"(q1), "=&v"(g2r), "=&v"(g2d) : "v"(vv_addr), "v"(ob_addr) : "memory")')
+        out.append("")
+    return "\n".join(out), report
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--check", action="store_true")
+    args = ap.parse_args()
+    text, report = generate()
+    if args.check:
+        if open(OUT).read() != text:
+            sys.exit(f"{OUT} is not what tools/gen_f32_trip.py generates: regenerate it")
+        print("ok")
+        return
+    with open(OUT, "w") as f:
+        f.write(text)
+    print("\n".join(report))
+
+
+if __name__ == "__main__":
+    main()
