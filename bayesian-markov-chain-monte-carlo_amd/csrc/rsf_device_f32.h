@@ -264,6 +264,12 @@ __device__ __forceinline__ bool step_fits(float rho, float dlt) {  // NaN fits (
   return !(__builtin_fabsf(rho) >= kRhoMax) && !(__builtin_fabsf(dlt) >= kDltMax);
 }
 
+// What a wave's solves ran, in steps (wave-uniform; the sampler adds them to rsf_mcmc_counters' steps_tight / steps_full /
+// steps_redone: incremental trips, full-evaluation trips — a wave holding chains of both forms runs both —, replayed trips).
+struct Trips32 {
+  uint32_t incr = 0, full = 0, redone = 0;
+};
+
 // State of the chains of a lane.  full[c]: chain c takes full evaluations — (ms, x) is its state, (w, Rh) stale; otherwise
 // (w, Rh, ms) is, x stale.
 template <typename V>
@@ -320,12 +326,39 @@ __device__ __forceinline__ unsigned lds_addr(const float *p) {
 }
 
 // Output of a solve: the sums of squares of the lane's chains and (one-chain form) the trajectory.
+// The sum of squares of float residuals is formed WITHOUT float64 instructions inside the solve:
+//   * in GROUPS of eight samples (k = 1..8, 9..16, ...; the last group may be short) the squares are summed in float32 —
+//     s = fma(r, r, s), for both chains of a lane one packed instruction;
+//   * the total is carried as an unevaluated sum of two floats (hi, lo), and a group's sum is added to it by the exact
+//     two-sum (Knuth): s = hi + x, bb = s - hi, e = (hi - (s - bb)) + (x - bb), lo += e, hi = s — ~48 bits;
+//   * the solve returns (double)hi + (double)lo.
+// (Until round 4 every residual was converted and squared in float64.  A float64 instruction among packed-float32 ones costs
+// the wave ~8 cycles beyond its issue slot when they come every few dozen instructions — tools/microbench_issue.hip — and
+// ~130 cycles each when they come once per trip after ~670 packed instructions: two conversions and two additions per trip
+// took 12 % of the sampler's time, profiles/r04/ab_f32_flush.log.)  A group's sum carries a relative rounding error of ~1e-7,
+// the total far less: inside what float32 residuals themselves carry.  The rule is by sample index, so it does not depend
+// on how the series is cut into chunks and trips; oracle/rsf_oracle.c restates it operation for operation.
 template <bool WANT_SSQ, bool WANT_ACC, typename V>
 struct Out32 {
-  double ssq[Vt<V>::N];
+  V hi, lo;  // the running total
+  V s32;     // the running group's sum
   double *acc_out;
   int64_t stride;
   V cv;
+  __device__ __forceinline__ void start(double total, bool any) {
+    typedef Vt<V> T;
+    const float h = any ? (float)total : 0.0f, l = any ? (float)(total - (double)h) : 0.0f;
+    hi = T::splat(h); lo = T::splat(l); s32 = T::splat(0.0f);
+  }
+  __device__ __forceinline__ void flush() {
+#pragma clang fp contract(off)
+    const V x = s32, s = hi + x, bb = s - hi, t = s - bb;
+    const V e1 = hi - t, e2 = x - bb;
+    lo = lo + (e1 + e2);
+    hi = s;
+    s32 = Vt<V>::splat(0.0f);
+  }
+  __device__ __forceinline__ double total(int c) const { return (double)Vt<V>::get(hi, c) + (double)Vt<V>::get(lo, c); }
   // sample k of the series (index kk of the staged chunk `ld`): dv = the interval's weighted sum of dV/dt in units of vk
   __device__ __forceinline__ void emit(int k, int kk, const float *ld, V dv, bool store) {
 #pragma clang fp contract(off)
@@ -335,12 +368,9 @@ struct Out32 {
       if (store) acc_out[(int64_t)k * stride] = (double)T::get(ak, 0);
     }
     if (WANT_SSQ) {
-      const float obs = ld[kk];
-#pragma unroll
-      for (int c = 0; c < T::N; ++c) {
-        const double r = (double)(T::get(ak, c) - obs);
-        ssq[c] = __builtin_fma(r, r, ssq[c]);
-      }
+      const V r = ak - T::splat(ld[kk]);
+      s32 = vfma(r, r, s32);
+      if ((k & 7) == 0) flush();
     }
   }
 };
@@ -350,8 +380,8 @@ struct Out32 {
 // computes is step_any's rule.  Every sample is emitted where it is computed — the sums of squares of the trip's start are
 // kept, so that a chain's sum holds the samples of the form the chain is in, added in series order whatever ran.
 template <bool DAMP, int NU, bool WANT_SSQ, bool WANT_ACC, typename V>
-__device__ __forceinline__ void trip32(State32<V> &s, const float *v, const float *ld, int k, int kk, const LaneV<V> &L,
-                                       Out32<WANT_SSQ, WANT_ACC, V> &out) {
+__device__ __forceinline__ void trip32(State32<V> &s, const float *v, const float *ld, int k, int kk, bool has_next, const LaneV<V> &L,
+                                       Out32<WANT_SSQ, WANT_ACC, V> &out, Trips32 &tc) {
 #pragma clang fp contract(off)
   typedef Vt<V> T;
   bool some_incr = false, some_full = false;
@@ -359,11 +389,10 @@ __device__ __forceinline__ void trip32(State32<V> &s, const float *v, const floa
   for (int c = 0; c < T::N; ++c) { some_incr |= !s.full[c]; some_full |= s.full[c]; }
   const bool wave_incr = __any(some_incr), wave_full = __any(some_full);
   const V w_s = s.w, Rh_s = s.Rh, ms_s = s.ms;
-  double ssq_s[T::N];
-#pragma unroll
-  for (int c = 0; c < T::N; ++c) ssq_s[c] = out.ssq[c];
+  const V hi_s = out.hi, lo_s = out.lo;
   bool redo = false;
   if (wave_incr) {
+    tc.incr += NU;
     bool left = false;  // may a chain of this lane that was incremental have met a step that does not fit?
     if constexpr (T::N == 2) {
       // The sampler's form: the NU steps, the emission of their samples and the trip's guard sums as ONE statement of
@@ -373,14 +402,19 @@ __device__ __forceinline__ void trip32(State32<V> &s, const float *v, const floa
       // The guard: sums of squares of the steps' end increments (two packed operations per step).  Below the squared
       // bounds, every step fitted (each square is at most the sum; squaring and adding round monotonically, the bounds are
       // powers of two); otherwise — a NaN sum included — the trip is replayed step by step under step_fits itself.
-      static_assert(NU == RSF_F32_TRIP_STEPS && WANT_SSQ && !WANT_ACC, "rsf_f32_trip.inc: eight steps, sums of squares only");
-      V g2r, g2d;
-      const unsigned vv_addr = lds_addr(v), ob_addr = lds_addr(ld + kk);
-      if constexpr (DAMP) RSF_F32_TRIP_DAMPED(s.w, s.Rh, s.ms, out.ssq[0], out.ssq[1], g2r, g2d, vv_addr, ob_addr);
-      else RSF_F32_TRIP_UNDAMPED(s.w, s.Rh, s.ms, out.ssq[0], out.ssq[1], g2r, g2d, vv_addr, ob_addr);
+      static_assert(NU == RSF_F32_TRIP_STEPS && NU == 8 && WANT_SSQ && !WANT_ACC, "rsf_f32_trip.inc: eight steps = one group of Out32, sums of squares only");
+      // The trip's table values are already in the private file: the trip before it read them ahead (each load placed
+      // behind the last reader of the registers it overwrites), the chunk's first trip's by solve32v's preload — so no trip
+      // starts by waiting for LDS.  This one reads ahead for the next (`has_next`; else its own again: stays inside the chunk).
+      V g2r, g2d, s32;  // (the trip is one group of the sum of squares, Out32: its float32 sum starts from zero)
+      const unsigned next_vv = lds_addr(v + (has_next ? 2 * NU : 0)), next_ob = lds_addr(ld + kk + (has_next ? NU : 0));
+      if constexpr (DAMP) RSF_F32_TRIP_DAMPED(s.w, s.Rh, s.ms, s32, g2r, g2d, next_vv, next_ob);
+      else RSF_F32_TRIP_UNDAMPED(s.w, s.Rh, s.ms, s32, g2r, g2d, next_vv, next_ob);
+      out.s32 = s32;
+      out.flush();
 #pragma unroll
-      for (int c = 0; c < T::N; ++c)
-        left |= !s.full[c] && !(T::get(g2r, c) < kRhoMax * kRhoMax && T::get(g2d, c) < kDltMax * kDltMax);
+      for (int c = 0; c < T::N; ++c)  // (no short circuits: straight-line code)
+        left |= !s.full[c] & !((T::get(g2r, c) < kRhoMax * kRhoMax) & (T::get(g2d, c) < kDltMax * kDltMax));
     } else {
       bool fits = true;
 #pragma unroll
@@ -395,22 +429,22 @@ __device__ __forceinline__ void trip32(State32<V> &s, const float *v, const floa
     redo = __any(left);
   }
   if (redo) {  // rare: the trip again from its start, step by step (identical results for the chains whose steps all fitted)
+    tc.redone += NU;
     s.w = w_s; s.Rh = Rh_s; s.ms = ms_s;
-#pragma unroll
-    for (int c = 0; c < T::N; ++c) out.ssq[c] = ssq_s[c];
+    out.hi = hi_s; out.lo = lo_s; out.s32 = T::splat(0.0f);
 #pragma unroll 1
     for (int j = 0; j < NU; ++j) out.emit(k + j, kk + j, ld, step_any<DAMP>(s, v[2 * j], v[2 * j + 1], v[2 * j + 2], L), true);
   } else if (wave_full) {
-    double ssq_i[T::N];  // the incremental chains' sums are final; the full chains' start again from the trip's start
-#pragma unroll
-    for (int c = 0; c < T::N; ++c) { ssq_i[c] = out.ssq[c]; out.ssq[c] = ssq_s[c]; }
+    tc.full += NU;
+    const V hi_i = out.hi, lo_i = out.lo;  // the incremental chains' sums are final; the full chains' start again from the trip's start
+    out.hi = hi_s; out.lo = lo_s; out.s32 = T::splat(0.0f);
     V msf = ms_s, xf = s.x;  // (the incremental trip advanced ms of every chain; the full chains' ms is the trip's start value)
 #pragma unroll
     for (int j = 0; j < NU; ++j) out.emit(k + j, kk + j, ld, rk4_full<DAMP>(msf, xf, v[2 * j], v[2 * j + 1], v[2 * j + 2], L), s.full[0]);
 #pragma unroll
     for (int c = 0; c < T::N; ++c) {
       if (s.full[c]) { T::set(s.ms, c, T::get(msf, c)); T::set(s.x, c, T::get(xf, c)); }
-      else out.ssq[c] = ssq_i[c];
+      else { T::set(out.hi, c, T::get(hi_i, c)); T::set(out.lo, c, T::get(lo_i, c)); }
     }
   }
 }
@@ -437,7 +471,7 @@ __device__ __forceinline__ void stage_chunk32(float *lds, const Consts &K, int k
 template <bool DAMP, bool WANT_SSQ, bool WANT_ACC, typename V>
 __device__ __forceinline__ void solve32v(float *lds, const Consts &K, bool resident, const bool (&active)[Vt<V>::N],
                                          const double (&dc)[Vt<V>::N], const double (&a)[Vt<V>::N], const double (&b)[Vt<V>::N],
-                                         double (&ssq)[Vt<V>::N], double *acc_out, int64_t stride) {
+                                         double (&ssq)[Vt<V>::N], double *acc_out, int64_t stride, Trips32 &tc) {
 #pragma clang fp contract(off)
   typedef Vt<V> T;
   constexpr int N = T::N;
@@ -460,15 +494,15 @@ __device__ __forceinline__ void solve32v(float *lds, const Consts &K, bool resid
     T::set(st.ms, c, S[c].ms0);
     st.full[c] = false;
   }
+  Trips32 lt;  // this solve's trips, as the lanes that take part see them
   Out32<WANT_SSQ, WANT_ACC, V> out;
   out.acc_out = acc_out; out.stride = stride; out.cv = L.cv;
-#pragma unroll
-  for (int c = 0; c < N; ++c) out.ssq[c] = 0.0;
+  double total0 = 0.0;
   if (WANT_SSQ && any) {
     const double d0 = (double)(float)K.data[0];
-#pragma unroll
-    for (int c = 0; c < N; ++c) out.ssq[c] = d0 * d0;
+    total0 = d0 * d0;
   }
+  out.start(total0, any);
   if (WANT_ACC && any) acc_out[0] = 0.0;
   for (int k0 = 1; k0 < K.nout; k0 += K.kc) {
     const int kn = min(K.kc, K.nout - k0);
@@ -476,9 +510,12 @@ __device__ __forceinline__ void solve32v(float *lds, const Consts &K, bool resid
     if (!any) continue;
     const float *ld = lds + lds_data_offset32(K);
     int kk = 0;
-    if (K.S == 1) {
+    if (K.S == 1 && (k0 & 7) == 1) {  // (a trip is one group of the sum of squares: chunks begin on a group boundary, rsf_set_model)
       constexpr int NU = 8;
-      for (; kk + NU <= kn; kk += NU) trip32<DAMP, NU>(st, lds + 2 * kk, ld, k0 + kk, kk, L, out);
+      if constexpr (N == 2) {
+        if (kn >= NU) RSF_F32_TRIP_PRELOAD(lds_addr(lds), lds_addr(ld));  // the chunk's first trip's table values (trip32)
+      }
+      for (; kk + NU <= kn; kk += NU) trip32<DAMP, NU>(st, lds + 2 * kk, ld, k0 + kk, kk, kk + 2 * NU <= kn, L, out, lt);
     }
     int j = 2 * K.S * kk;
     for (; kk < kn; ++kk) {
@@ -487,8 +524,16 @@ __device__ __forceinline__ void solve32v(float *lds, const Consts &K, bool resid
       out.emit(k0 + kk, kk, ld, dv, true);
     }
   }
+  if (WANT_SSQ) out.flush();  // the last, short group
 #pragma unroll
-  for (int c = 0; c < N; ++c) ssq[c] = out.ssq[c];
+  for (int c = 0; c < N; ++c) ssq[c] = out.total(c);
+  const unsigned long long who = __builtin_amdgcn_ballot_w64(any);  // (lanes without an active chain ran no trip)
+  if (who != 0) {
+    const int src = __builtin_ctzll(who);
+    tc.incr += __builtin_amdgcn_readlane(lt.incr, src);
+    tc.full += __builtin_amdgcn_readlane(lt.full, src);
+    tc.redone += __builtin_amdgcn_readlane(lt.redone, src);
+  }
 }
 
 // one chain per lane
@@ -498,7 +543,8 @@ __device__ __forceinline__ double solve32(float *lds, const Consts &K, bool resi
   const bool act[1] = {active};
   const double dcs[1] = {dc}, as[1] = {a}, bs[1] = {b};
   double ssq[1];
-  solve32v<DAMP, WANT_SSQ, WANT_ACC, float>(lds, K, resident, act, dcs, as, bs, ssq, acc_out, stride);
+  Trips32 tc;
+  solve32v<DAMP, WANT_SSQ, WANT_ACC, float>(lds, K, resident, act, dcs, as, bs, ssq, acc_out, stride, tc);
   return ssq[0];
 }
 
@@ -506,8 +552,8 @@ __device__ __forceinline__ double solve32(float *lds, const Consts &K, bool resi
 // the assembly trip owns the registers above (trip32).
 template <bool DAMP>
 __device__ __forceinline__ void solve32x2(float *lds, const Consts &K, bool resident, const bool (&active)[2], const double (&dc)[2],
-                                          const double (&a)[2], const double (&b)[2], double (&ssq)[2]) {
-  solve32v<DAMP, true, false, float2v>(lds, K, resident, active, dc, a, b, ssq, nullptr, 0);
+                                          const double (&a)[2], const double (&b)[2], double (&ssq)[2], Trips32 &tc) {
+  solve32v<DAMP, true, false, float2v>(lds, K, resident, active, dc, a, b, ssq, nullptr, 0, tc);
 }
 
 }  // namespace f32

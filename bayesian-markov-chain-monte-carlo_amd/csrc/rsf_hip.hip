@@ -635,6 +635,9 @@ int rsf_set_model(rsf_ctx *c, const rsf_model *m) {
     kc = ((int64_t)words - 2) / (2 * (int64_t)S + 1);
     if (kc < 1) return fail(RSF_ERR_UNSUPPORTED, "rsf_set_model: substeps=%d does not fit the LDS staging budget", S);
     if (kc > nout - 1) kc = nout - 1;
+    // float32 solve: residuals are summed in float32 over groups of eight samples (k = 1..8, 9..16, ...; rsf_device_f32.h,
+    // Out32) and its assembly trip covers one group: chunks begin on a group boundary
+    if ((m->flags & RSF_FLAG_FP32_SOLVE) && kc < nout - 1 && kc >= 8) kc &= ~(int64_t)7;
     // chain-independent loading velocity at every RK4 stage time, RateStateModel.py:327-329
     vl.resize(2 * (size_t)S * (size_t)(nout - 1) + 1);
     for (size_t j = 0; j < vl.size(); ++j) {

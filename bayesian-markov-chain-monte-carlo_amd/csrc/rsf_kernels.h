@@ -828,7 +828,8 @@ mcmc_f32x2_kernel(Consts K, McmcArgs A) {  // (the registers above that count: t
     }
     if (kWinRegs && A.adapt_mode != RSF_ADAPT_NONE && c.valid) load_window(s, t);
   }
-  uint32_t n_acc = 0, n_eval = 0, n_nonfinite = 0, n_oob = 0;  // (the tier / wave counters belong to the float64 RK4 step)
+  uint32_t n_acc = 0, n_eval = 0, n_nonfinite = 0, n_oob = 0, n_solves = 0;
+  rsf::f32::Trips32 trips;  // wave-uniform: what the wave's solves ran (steps_tight = incremental, steps_full, steps_redone)
 
   float *lds32 = reinterpret_cast<float *>(lds);
   if (resident) rsf::f32::stage_chunk32(lds32, K, 1, K.nout - 1);
@@ -887,7 +888,8 @@ mcmc_f32x2_kernel(Consts K, McmcArgs A) {  // (the registers above that count: t
       double dcn[2], an[2], bn[2];
 #pragma unroll
       for (int s = 0; s < 2; ++s) { dcn[s] = qn[s][0]; an[s] = D == 3 ? qn[s][D - 2] : K.a_def; bn[s] = D == 3 ? qn[s][D - 1] : K.b_def; }
-      rsf::f32::solve32x2<DAMP>(lds32, K, resident, inb, dcn, an, bn, ssqn);
+      rsf::f32::solve32x2<DAMP>(lds32, K, resident, inb, dcn, an, bn, ssqn, trips);
+      ++n_solves;
     }
 #pragma unroll
     for (int s = 0; s < NC; ++s) {
@@ -985,6 +987,10 @@ mcmc_f32x2_kernel(Consts K, McmcArgs A) {  // (the registers above that count: t
     if (s1) atomicAdd(&A.stats[RSF_CNT_EVALUATED], s1);
     if (s2) atomicAdd(&A.stats[RSF_CNT_NONFINITE], s2);
     if (s3) atomicAdd(&A.stats[RSF_CNT_OUT_OF_BOUNDS], s3);
+    if (n_solves) atomicAdd(&A.stats[RSF_CNT_WAVE_SOLVES], (unsigned long long)n_solves);
+    if (trips.incr) atomicAdd(&A.stats[RSF_CNT_STEPS_TIGHT], (unsigned long long)trips.incr);
+    if (trips.full) atomicAdd(&A.stats[RSF_CNT_STEPS_FULL], (unsigned long long)trips.full);
+    if (trips.redone) atomicAdd(&A.stats[RSF_CNT_STEPS_REDONE], (unsigned long long)trips.redone);
   }
 }
 

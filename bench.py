@@ -496,8 +496,10 @@ def main():
                        "early_rejected_of_evaluated": stats["counters"]["early_rejected"] / max(1, stats["counters"]["evaluated"]),
                        "lane_utilisation": stats["counters"]["lane_utilisation"],
                        "wave_steps_vs_full_series": (sum(stats["counters"]["steps_" + t] for t in ("tight", "narrow", "wide", "full"))
-                                                     / max(1, stats["counters"]["wave_solves"] * (nout - 1))) if mode == "RK4" else None,
-                       "tier_wave_steps": {t: stats["counters"]["steps_" + t] for t in ("tight", "narrow", "wide", "full")}},
+                                                     / max(1, stats["counters"]["wave_solves"] * (nout - 1))) if mode in ("RK4", "RK4/f32") else None,
+                       # (float32 solve: tight = incremental trips, full = full-evaluation trips — a wave holding chains of both forms
+                       #  runs both —, redone = trips replayed step by step because a chain left the incremental form in them)
+                       "tier_wave_steps": {t: stats["counters"]["steps_" + t] for t in ("tight", "narrow", "wide", "full", "redone")}},
             "roofline": valu, "roofline_hbm": hbm,
         }
         out["previous_round"] = previous_round_line(out["config"]["workload"], value)

@@ -224,6 +224,10 @@ int rsf_mcmc_stats(rsf_ctx *ctx, int64_t *n_accepted, int64_t *n_evaluated, int6
 #define RSF_CNT_STEPS_WIDE 9     /*   FULL = log / exp / reciprocal at every stage (stiff small-Dc lanes)                */
 #define RSF_CNT_STEPS_FULL 10
 #define RSF_CNT_STEPS_REDONE 11  /* wave-steps of incremental trips thrown away because a lane left the tier's guard region */
+                                 /* float32 solve (RSF_FLAG_FP32_SOLVE, two chains per lane): STEPS_TIGHT = wave-steps of incremental
+                                    trips, STEPS_FULL = of full-evaluation trips (a wave holding chains of both forms runs both),
+                                    STEPS_REDONE = of trips replayed step by step because a chain left the incremental form in them;
+                                    NARROW / WIDE / EARLY_REJECTED / LANE_STEPS stay 0 there */
 #define RSF_CNT_LANE_STEPS 12    /* sum over wave-steps of the lanes still integrating: lane utilisation =
                                     LANE_STEPS / (64 * (STEPS_TIGHT + STEPS_NARROW + STEPS_WIDE + STEPS_FULL)) */
 #define RSF_CNT_COUNT 13

@@ -235,7 +235,8 @@ static double solve_dop853(const rsf_ctx *c, double dc, double a, double b, cons
  * arithmetic, one rounding per operation (fmaf where the formula is a fused multiply-add).  It restates the float32
  * FORMULATION of the product (csrc/rsf_device_f32.h), not an independent algorithm: the rescaled state ms = mu/k',
  * x = V_ref theta/Dc, the acceleration sample from the step's velocity increment (differencing two float velocities near
- * V_ref would lose four digits), float tables, a double sum of squares of float residuals — and the product's rule for HOW a
+ * V_ref would lose four digits), float tables, the squares of float residuals summed in float over groups of eight samples
+ * and the groups' sums in a pair of floats by the exact two-sum — and the product's rule for HOW a
  * chain takes a step (round 4), which is a function of the chain's own parameters and trajectory only:
  *   - incrementally (incr_step32): state (w, Rh = (h/2Dc)/x), every stage reached from the step's start by short series,
  *     no transcendental function — while the step's END increments satisfy |rho| < 2^-10 and |dlt| < 2^-7 (NaN passes);
@@ -353,9 +354,11 @@ static double solve_f32(const rsf_ctx *c, double dc, double a, double b, const d
   float ms = (float)(m->mu_t_zero / kprime), x = 1.0f, w = (float)exp((m->mu_t_zero - m->mu_ref) * inv_a), Rh = L.hhd;
   int full = 0;
   double ssq = 0.0;
+  float s32 = 0.0f;
   int64_t j = 0;
   if (acc) acc[0] = 0.0;
-  if (data) { double d0 = (double)(float)data[0]; ssq = d0 * d0; }
+  float hi = 0.0f, lo = 0.0f;
+  if (data) { double d0 = (double)(float)data[0]; ssq = d0 * d0; hi = (float)ssq; lo = (float)(ssq - (double)hi); }
   for (int32_t k = 1; k < c->nout; ++k) {
     float dv = 0.0f;
     for (int s = 0; s < S; ++s, j += 2) {
@@ -376,8 +379,22 @@ static double solve_f32(const rsf_ctx *c, double dc, double a, double b, const d
     }
     float ak = dv * L.cv;                                                /* RateStateModel.py:388, from the increment */
     if (acc) acc[k * stride] = (double)ak;
-    if (data) { double r = (double)(ak - (float)data[k]); ssq = fma(r, r, ssq); }
+    if (data) {
+      /* float residuals, squared and summed in float within a group of eight samples (k = 1..8, 9..16, ...; the last may be
+       * short); the total carried as an unevaluated sum of two floats, a group's sum added to it by the exact two-sum
+       * (csrc/rsf_device_f32.h, Out32): no double arithmetic inside the solve */
+      float r = ak - (float)data[k];
+      s32 = fmaf(r, r, s32);
+      if ((k & 7) == 0 || k == c->nout - 1) {
+        float x = s32, sm = hi + x, bb = sm - hi, t = sm - bb;
+        float e1 = hi - t, e2 = x - bb;
+        lo = lo + (e1 + e2);
+        hi = sm;
+        s32 = 0.0f;
+      }
+    }
   }
+  if (data) ssq = (double)hi + (double)lo;
   return ssq;
 }
 

@@ -75,7 +75,13 @@ def main():
     print(f"chains={C} nsteps={args.nsteps} substeps={args.substeps} iters/launch={ips} rounds={args.rounds} params={d} {args.precision}")
     for name, t in times.items():
         med, mn = float(np.median(t)), float(np.min(t))
-        print(f"  {name:16s} median {med:9.3f} ms  min {mn:9.3f} ms   {work / (med * 1e-3):.4e} steps*chains/s")
+        line = f"  {name:16s} median {med:9.3f} ms  min {mn:9.3f} ms   {work / (med * 1e-3):.4e} steps*chains/s"
+        try:   # where the wave-steps went (builds that have rsf_mcmc_counters)
+            c = engines[name].counters()
+            line += "   wave-steps " + " ".join(f"{k[6:]}={c[k]:.3g}" for k in ("steps_tight", "steps_narrow", "steps_wide", "steps_full", "steps_redone") if c.get(k))
+        except Exception:
+            pass
+        print(line)
 
 
 if __name__ == "__main__":

@@ -38,17 +38,18 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, "bayesian-markov-chain-monte-carlo_amd", "csrc", "rsf_f32_trip.inc")
 
 NU = 8
+PREFETCH = os.environ.get("RSF_TRIP_PREFETCH", "1") != "0"   # (0: an experiment — every trip reads its own tables first and waits)
 ISSUE = 4                              # cycles between two issues of one wave
-# Spacing the list scheduler aims for between an instruction and the first reader of its result, by kind (packed float /
-# scalar float / float64).  Not measured latencies: a reader directly behind its producer costs one cycle (header), and with
+# Spacing the list scheduler aims for between an instruction and the first reader of its result (every operation of the
+# trip is a packed-float one: a float64 or scalar instruction among them costs the wave ~8 cycles, tools/microbench_issue.hip).  Not measured latencies: a reader directly behind its producer costs one cycle (header), and with
 # these targets the scheduler keeps them apart wherever the dataflow offers something else to issue.
-LAT = {"pk": 10, "f": 6, "d": 8}
-COMPILER_VGPRS = 160                   # amdgpu_num_vgpr of the sampler kernel; the private file is v[160:255]
+LAT = {"pk": 10}
+COMPILER_VGPRS = 160                   # the sampler kernel is limited to v0..v159 (amdgpu_num_vgpr = half of this); the private file is v[160:255]
 PRIV0 = COMPILER_VGPRS
 CONSTS = ["hhd", "hd", "khh", "kh", "kh6", "boa", "nhboa", "kvk", "bh", "cv", "vref", "h6", "c16", "c13"]
 # in/out operands of the trip statement, in this order; then the two LDS byte addresses
-OPERANDS = ["w", "Rh", "ms", "q0", "q1", "g2r", "g2d"]
-ADDR_VV, ADDR_OB = len(OPERANDS), len(OPERANDS) + 1
+OPERANDS = ["w", "Rh", "ms", "s32", "g2r", "g2d"]
+ADDR_VV, ADDR_OB = len(OPERANDS), len(OPERANDS) + 1      # the NEXT trip's tables (prefetched while this trip computes)
 
 
 class Src:
@@ -81,8 +82,7 @@ def build(damp):
         return name
 
     w, Rh, ms = "w", "Rh", "ms"            # operand names: the state at the trip's start
-    q = ["q0", "q1"]
-    g2r = g2d = None
+    g2r = g2d = s32 = None
     for j in range(NU):
         s = f"_{j}"
 
@@ -151,10 +151,12 @@ def build(damp):
             g2r = op("g2r" + s, "pk", "fma", [T(rhoE), T(rhoE), T(g2r)], j, dest_fixed="g2r")
             g2d = op("g2d" + s, "pk", "fma", [T(dlE), T(dlE), T(g2d)], j, dest_fixed="g2d")
         ak = mul("ak", T(dv), C("cv"))        # RateStateModel.py:388, from the interval's velocity increment
-        for c in range(2):
-            rs = op(f"rs{c}{s}", "f", "sub", [Src("half", (ak, c)), Src("ob", j)], j)
-            rd = op(f"rd{c}{s}", "d", "cvt", [T(rs)], j)
-            q[c] = op(f"q{c}{s}", "d", "fma64", [T(rd), T(rd), T(q[c])], j, dest_fixed=f"q{c}")
+        # residuals of both chains and the group's float32 sum of their squares (rsf_device_f32.h, Out32): packed, like all else
+        r = op("r" + s, "pk", "add", [T(ak), Src("ob", j, True)], j)
+        if s32 is None:
+            s32 = op("s32" + s, "pk", "mul", [T(r), T(r)], j, dest_fixed="s32")
+        else:
+            s32 = op("s32" + s, "pk", "fma", [T(r), T(r), T(s32)], j, dest_fixed="s32")
         w, Rh, ms = wn, Rhn, msn
     final = {"w": w, "Rh": Rh, "ms": ms}
     return ops, by, final
@@ -237,6 +239,7 @@ def emit_asm(order, by, final, regs):
     where = {name: f"%{i}" for i, name in enumerate(OPERANDS)}     # operands print as %N (register pairs)
     phys = {}
     lines = []
+    reads = []   # per line: the table registers it reads
     for i, o in enumerate(order):
         # destination
         if o.dest_fixed:
@@ -253,6 +256,7 @@ def emit_asm(order, by, final, regs):
             fixed = by[name].dest_fixed
             return where[fixed]
 
+        tab = set()
         if o.kind == "pk":
             n = len(o.srcs)
             txt, sel, selhi, neg = [], [0] * n, [1] * n, [0] * n
@@ -263,6 +267,12 @@ def emit_asm(order, by, final, regs):
                     txt.append(pair(regs.const[s.val]))
                 elif s.kind == "vl":          # one float of the table, for both chains: the register pair that holds it, one half
                     r = regs.vv + s.val
+                    tab.add(r)
+                    txt.append(pair(r & ~1))
+                    sel[k], selhi[k] = r & 1, r & 1
+                elif s.kind == "ob":          # the observation of step s.val, for both chains
+                    r = regs.ob + s.val
+                    tab.add(r)
                     txt.append(pair(r & ~1))
                     sel[k], selhi[k] = r & 1, r & 1
                 elif s.kind == "imm":
@@ -277,15 +287,8 @@ def emit_asm(order, by, final, regs):
             if any(neg):
                 mods += " neg_lo:[" + ",".join(map(str, neg)) + "] neg_hi:[" + ",".join(map(str, neg)) + "]"
             ins = f"v_pk_{o.opcode}_f32 {dst}, " + ", ".join(txt) + mods
-        elif o.opcode == "sub":                # residual of one chain: its half of ak minus the observation
-            (akname, c), j = o.srcs[0].val, o.srcs[1].val
-            ins = f"v_sub_f32_e32 {dst}, v{phys[akname] + c}, v{regs.ob + j}"
-        elif o.opcode == "cvt":
-            ins = f"v_cvt_f64_f32_e32 {dst}, v{phys[o.srcs[0].val]}"
-        elif o.opcode == "fma64":
-            r = loc(o.srcs[0].val)
-            ins = f"v_fma_f64 {dst}, {r}, {r}, {dst}"
         lines.append(ins)
+        reads.append(tab)
         # registers whose value is dead after this instruction
         for s in dict.fromkeys(op_deps(o)):   # (in order: the register assignment must not depend on hash seeds)
             if last_use.get(s) == i and s in phys:
@@ -294,17 +297,25 @@ def emit_asm(order, by, final, regs):
             regs.free(phys.pop(o.name))
     for k, v in final.items():
         lines.append(f"v_pk_mov_b32 {where[k]}, {pair(phys[v])}, {pair(phys[v])} op_sel:[0,1]")
-    return lines
+        reads.append(set())
+    if not PREFETCH:
+        return [l for l, _ in loads(regs, ADDR_VV, ADDR_OB)] + ["s_waitcnt lgkmcnt(0)", ".p2align 3"] + lines
+    # the NEXT trip's table values: each load as soon as the registers it overwrites have been read for the last time
+    out = list(zip(lines, reads))
+    for ins, dest in reversed(loads(regs, ADDR_VV, ADDR_OB)):
+        last = max((i for i, (_, rd) in enumerate(out) if rd & dest), default=-1)
+        out.insert(last + 1, (ins, set()))
+    return [l for l, _ in out]
 
 
-def loads(regs):
+def loads(regs, op_vv, op_ob):
+    """ds_read instructions of one trip's tables into the private file: (instruction, set of destination registers)."""
     out = []
     for i in range(0, 2 * NU, 4):
-        out.append(f"ds_read_b128 v[{regs.vv + i}:{regs.vv + i + 3}], %{ADDR_VV}" + (f" offset:{4 * i}" if i else ""))
-    out.append(f"ds_read_b32 v{regs.vv + 2 * NU}, %{ADDR_VV} offset:{8 * NU}")
+        out.append((f"ds_read_b128 v[{regs.vv + i}:{regs.vv + i + 3}], %{op_vv}" + (f" offset:{4 * i}" if i else ""), set(range(regs.vv + i, regs.vv + i + 4))))
+    out.append((f"ds_read_b32 v{regs.vv + 2 * NU}, %{op_vv} offset:{8 * NU}", {regs.vv + 2 * NU}))
     for j in range(0, NU, 2):
-        out.append(f"ds_read2_b32 v[{regs.ob + j}:{regs.ob + j + 1}], %{ADDR_OB} offset0:{j} offset1:{j + 1}")
-    out.append("s_waitcnt lgkmcnt(0)")
+        out.append((f"ds_read2_b32 v[{regs.ob + j}:{regs.ob + j + 1}], %{op_ob} offset0:{j} offset1:{j + 1}", {regs.ob + j, regs.ob + j + 1}))
     return out
 
 
@@ -336,29 +347,99 @@ def generate():
     out.append("\n".join(f'      "{l}\\n\\t" \\' for l in setup))
     out.append("      : : " + ", ".join(f'"v"((L).{c})' for c in names) + ' : "v255")')
     out.append("")
+    out.append("// the tables of a chunk's FIRST trip → the private file (every later trip's are prefetched by the trip before it)")
+    out.append("#define RSF_F32_TRIP_PRELOAD(vv_addr, ob_addr) \\")
+    out.append("  asm volatile( \\")
+    out.append("\n".join(f'      "{l}\\n\\t" \\' for l, _ in loads(regs0, 0, 1)))
+    out.append('      : : "v"(vv_addr), "v"(ob_addr) : "memory")')
+    out.append("")
     report = []
     for damp in (True, False):
         ops, by, final = build(damp)
         order, cycles = schedule(ops, by)
         regs = Regs()
-        body = loads(regs) + emit_asm(order, by, final, regs)
+        # Every instruction of the trip is 8 bytes long (VOP3P).  Begun on a 4-byte boundary — as the code before the statement
+        # leaves it half the time — the same stream takes 5.07 cycles per instruction instead of 4.06 (an instruction that
+        # straddles a fetch boundary costs the wave extra; profiles/r04/ab_f32_alignment.log: the kernel 21.7 ms against 19.2 ms
+        # with one, three, seven or fifteen s_nop in front of the body).  The assembler pads code with s_nop.
+        # (the s_waitcnt is a 4-byte instruction: the alignment comes behind it)
+        body = (["s_waitcnt lgkmcnt(0)"] if PREFETCH else []) + [".p2align 3"] + emit_asm(order, by, final, regs)
         npk = sum(o.kind == "pk" for o in ops)
         tag = "DAMPED" if damp else "UNDAMPED"
         report.append(f"{tag.lower()}: {len(ops)} operations ({npk} packed), model {cycles} cycles = {cycles / NU:.0f} per step; private file: "
                       f"{2 * len(CONSTS)} constants + {2 * NU + 2 + NU} table + {2 * regs.max_used} of {2 * regs.n_pool} temporaries")
         out.append(f"// {report[-1]}")
-        out.append(f"#define RSF_F32_TRIP_{tag}(w, Rh, ms, q0, q1, g2r, g2d, vv_addr, ob_addr) \\")
+        out.append(f"#define RSF_F32_TRIP_{tag}(w, Rh, ms, s32, g2r, g2d, next_vv_addr, next_ob_addr) \\")
         out.append("  asm volatile( \\")
         out.append("\n".join(f'      "{l}\\n\\t" \\' for l in body))
-        out.append('      : "+v"(w), "+v"(Rh), "+v"(ms), "+v"(q0), "+v"(q1), "=&v"(g2r), "=&v"(g2d) : "v"(vv_addr), "v"(ob_addr) : "memory")')
+        out.append('      : "+v"(w), "+v"(Rh), "+v"(ms), "=&v"(s32), "=&v"(g2r), "=&v"(g2d) : "v"(next_vv_addr), "v"(next_ob_addr) : "memory")')
         out.append("")
     return "\n".join(out), report
+
+
+ALIGN = os.environ.get("RSF_TRIP_ALIGN", ".p2align 3")   # (experiments: ".p2align 3\ns_nop 0" starts the body on a 4-byte boundary)
+
+
+def bench_variants(path):
+    """Mutated copies of the damped trip for tools/microbench_trip.hip (results are garbage: only the time is looked at):
+    A: every source a fixed register (no dependencies, no variety of sources);  B: destinations redirected to a rotating set of
+    eight pairs (no dependencies, the sources' variety kept);  C: the original instructions in a shuffled order."""
+    import random
+    import re
+    ops, by, final = build(True)
+    order, _ = schedule(ops, by)
+    regs = Regs()
+    body = emit_asm(order, by, final, regs)
+    valu = [l for l in body if l.startswith("v_pk_")]
+    rnd = random.Random(1)
+    out = ["// GENERATED by tools/gen_f32_trip.py --bench: timing variants of the damped trip (not part of the product)"]
+
+    def macro(name, lines):
+        out.append(f"#define RSF_F32_TRIP_BENCH_{name}() \\")
+        out.append("  asm volatile( \\")
+        out.append("\n".join(f'      "{l}\\n\\t" \\' for l in [ALIGN] + lines))
+        out.append('      : : : "memory")')
+        out.append("")
+
+    def fix_operands(l):   # operands of the statement → private registers
+        return re.sub(r"%(\d+)", lambda m: pair(PRIV0 + 2 * int(m.group(1))), l)
+
+    base = [fix_operands(l) for l in valu]
+    macro("ORIGINAL", base)
+    a = []
+    for l in base:
+        head, rest = l.split(" ", 1)
+        parts = rest.split(", ")
+        dst, srcs = parts[0], parts[1:]
+        tail = ""
+        if " " in srcs[-1]:
+            srcs[-1], tail = srcs[-1].split(" ", 1)
+            tail = " " + tail
+        fixed = [pair(PRIV0 + 2 * k) for k in range(len(srcs))]
+        a.append(f"{head} {dst}, " + ", ".join(fixed) + tail)
+    macro("FIXED_SOURCES", a)
+    b = []
+    for i, l in enumerate(base):
+        head, rest = l.split(" ", 1)
+        dst, others = rest.split(", ", 1)
+        b.append(f"{head} {pair(240 + 2 * (i % 8))}, {others}")
+    macro("ROTATING_DESTINATIONS", b)
+    c = list(base)
+    rnd.shuffle(c)
+    macro("SHUFFLED", c)
+    with open(path, "w") as f:
+        f.write("\n".join(out) + "\n")
+    print(f"{len(base)} instructions per variant -> {path}")
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--check", action="store_true")
+    ap.add_argument("--bench", metavar="FILE", help="write timing variants of the damped trip (tools/microbench_trip.hip)")
     args = ap.parse_args()
+    if args.bench:
+        bench_variants(args.bench)
+        return
     text, report = generate()
     if args.check:
         if open(OUT).read() != text:

@@ -19,7 +19,7 @@ for d in ("a", "b", "c"):
     per = collections.OrderedDict()
     for f in glob.glob(f"{out}/{d}/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
-            if "mcmc_kernel" in r["Kernel_Name"]:
+            if "mcmc_" in r["Kernel_Name"] and "kernel" in r["Kernel_Name"] and "propose" not in r["Kernel_Name"]:  # the sampler kernels (float64, float32 two-chain)
                 per.setdefault(int(r["Dispatch_Id"]), collections.defaultdict(float))[r["Counter_Name"]] += float(r["Counter_Value"])
     for i, disp in enumerate(sorted(per)):
         if i < n:
