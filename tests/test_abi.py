@@ -179,3 +179,15 @@ def test_generated_trip_is_current():
 
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_f32_trip.py"), "--check"], capture_output=True, text=True)
     assert out.returncode == 0 and out.stdout.strip() == "ok", out.stdout + out.stderr
+
+
+def test_float32_trip_owns_its_private_register_file():
+    """The float32 sampler's assembly trip keeps constants, tables and temporaries in v[160:255] across statements.  That is
+    sound only while compiled code never touches those registers, the kernel uses no AGPR, nothing spills inside the trip loop
+    and the trip's 8-byte instruction stream starts on an 8-byte boundary: tools/check_private_file.py compiles one
+    instantiation (no GPU) and checks all four in the ISA."""
+    import subprocess
+    import sys
+
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_private_file.py")], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stdout + out.stderr[-2000:]
