@@ -10,7 +10,8 @@ intervals.  Inputs (observation, loading table, chain state) are resident in HBM
 region.  metric = chains × proposals × nsteps / wall seconds, whole job (all ranks).
 
 Default workload: BASELINE.json configs[2] (262 144 chains x nsteps 2000, fp64) — the largest configuration that
-fits one GPU; the configs[1] shape is measured in the same process afterwards and carried under "also".
+fits one GPU; the configs[1] shape, the reference's own main.py sweep and one GPU's share of configs[4] (float64 and float32 solve)
+are measured in the same process afterwards and carried under "also".
 
 N > 1: one rank per GPU under torch.distributed.run.  `python bench.py --gpus N` without that launcher starts it
 itself: the parent touches no GPU API, spawns `python -m torch.distributed.run --nproc-per-node N bench.py ...`
@@ -530,6 +531,23 @@ def main():
                 # the data-dependent bad case next to the headline's good one: the reference's own main.py problem
                 cfg1_rate = out["also"]["cfg1"]["value"] if "cfg1" in out["also"] else value
                 out["also"]["main_py_sweep"] = main_py_sweep(pkg, headline_rate=cfg1_rate)
+                # BASELINE configs[4] ("joint (a, b, d_c), nsteps=4000, float32 vs float64 tolerance sweep"): one GPU's share of it, both
+                # precisions, three launches each — the init kernel's own proposal covariance and adaptive Metropolis, nothing hand-set
+                out["also"]["cfg5"] = {}
+                w5 = WORKLOADS["cfg5"]
+                model5, data5 = synthetic_problem(w5["nsteps"])
+                for prec in ("float64", "float32"):
+                    model5.precision = prec
+                    w_5, kms_5, st_5, eng_5, tr_5, _ = time_sampler(pkg, model5, data5, w5["chains"], ips, 3, 1, 0, barrier, w5["n_params"])
+                    out["also"]["cfg5"][prec] = {
+                        "workload": w5["desc"] + (" [float32 solve, float64 sampler]" if prec == "float32" else ""),
+                        "value": w5["chains"] * ips * 3 * w5["nsteps"] / w_5, "unit": "ODE-steps*chains/s", "steps": 3, "ms_per_step": w_5 / 3 * 1e3,
+                        "kernel_ms": kms_5, "evaluated_fraction": st_5["evaluated"] / max(1, st_5["iters_done"] * w5["chains"]),
+                        "tier_wave_steps": {t: st_5["counters"]["steps_" + t] for t in ("tight", "narrow", "wide", "full", "redone")}}
+                    eng_5.close()
+                    del tr_5
+                    torch.cuda.empty_cache()
+                model5.precision = "float64"
         if not args.no_cpu_baseline and d == 1 and mode == "RK4":
             out["reference_scheme"] = reference_scheme_rate(model, data, C, nsteps)
             out["cpu_baseline"] = cpu_baseline(model, data)
