@@ -935,7 +935,8 @@ def test_float32_sampler_two_chains_per_lane(pkg, oracle_lib, oracle_mod, d, C, 
     np.testing.assert_allclose(tg[1][:, same], tc[1][:, same], rtol=1e-6)
 
 
-def test_float32_step_forms_mixed_in_one_wave(pkg, oracle_lib, oracle_mod):
+@pytest.mark.parametrize("damping", [True, False])
+def test_float32_step_forms_mixed_in_one_wave(pkg, oracle_lib, oracle_mod, damping):
     """The float32 solve's two step forms (csrc/rsf_device_f32.h): a chain integrates incrementally — no transcendental
     function; in the sampler as scheduled assembly over a private register file (rsf_f32_trip.inc) — until one of its own
     steps leaves the guard, and by full evaluations from that step on.  Chains of every kind side by side: Dc from 8 (full
@@ -950,7 +951,7 @@ def test_float32_step_forms_mixed_in_one_wave(pkg, oracle_lib, oracle_mod):
         one-chain forward kernel's at that point, for every kind of chain;
     (c) the sampler's chains against the restatement run as a sampler: same decisions in >= 99 % of the chains."""
     n, C = 500, 1792
-    m = _models(oracle_mod, n)
+    m = _models(oracle_mod, n, 1, damping)   # (both variants of the generated trip: with and without the radiation damping pass)
     m.precision = "float32"
     kinds = np.array([8.0, 1200.0, 60.0, 3000.0, 130.0, 500.0, 25.0])
     rng = np.random.default_rng(21)
@@ -958,7 +959,7 @@ def test_float32_step_forms_mixed_in_one_wave(pkg, oracle_lib, oracle_mod):
     with pkg.Engine(mem="host") as g, pkg.Engine(lib=oracle_lib) as c, pkg.Engine(lib=oracle_lib) as c64:
         for e in (g, c):
             e.set_model(m, 1)
-        c64.set_model(_models(oracle_mod, n), 1)
+        c64.set_model(_models(oracle_mod, n, 1, damping), 1)
         data = synthetic_data(c64)
         # (a)
         sg, ag = g.forward(dc0, data=data, want_ssq=True, want_acc=True)
