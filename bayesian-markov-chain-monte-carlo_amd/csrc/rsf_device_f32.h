@@ -414,7 +414,7 @@ __device__ __forceinline__ void trip32(State32<V> &s, const float *v, const floa
       out.flush();
 #pragma unroll
       for (int c = 0; c < T::N; ++c)  // (no short circuits: straight-line code)
-        left |= !s.full[c] & !((T::get(g2r, c) < kRhoMax * kRhoMax) & (T::get(g2d, c) < kDltMax * kDltMax));
+        left |= (int)!s.full[c] & (int)!((int)(T::get(g2r, c) < kRhoMax * kRhoMax) & (int)(T::get(g2d, c) < kDltMax * kDltMax));
     } else {
       bool fits = true;
 #pragma unroll
@@ -515,7 +515,32 @@ __device__ __forceinline__ void solve32v(float *lds, const Consts &K, bool resid
       if constexpr (N == 2) {
         if (kn >= NU) RSF_F32_TRIP_PRELOAD(lds_addr(lds), lds_addr(ld));  // the chunk's first trip's table values (trip32)
       }
-      for (; kk + NU <= kn; kk += NU) trip32<DAMP, NU>(st, lds + 2 * kk, ld, k0 + kk, kk, kk + 2 * NU <= kn, L, out, lt);
+      while (kk + NU <= kn) {
+        if constexpr (N == 2) {
+          // All of the chunk's trips but the last in ONE statement (rsf_f32_trip.inc, RSF_F32_TRIPS_LOOP_*), while no chain of the
+          // wave takes full evaluations: what compiled code does between two trips — guard test, the group's sum into the
+          // total, addresses, loop control — is ~25 instructions of the statement's own instead of ~60.  It comes back early,
+          // with the state of the failing trip's START, when a guard sum is not below its bound; that trip then goes through
+          // trip32 like any other (which replays it step by step) — after its tables, overwritten by the read-ahead, are read again.
+          int n = (kn - kk) / NU - 1;
+          bool some_full = false;
+#pragma unroll
+          for (int c = 0; c < N; ++c) some_full |= st.full[c];
+          if (n > 0 && !__any(some_full)) {
+            const int n0 = n;
+            unsigned vv_next = lds_addr(lds + 2 * (kk + NU)), ob_next = lds_addr(ld + kk + NU);
+            unsigned long long m0, m1;
+            const float t2r = kRhoMax * kRhoMax, t2d = kDltMax * kDltMax;
+            if constexpr (DAMP) RSF_F32_TRIPS_LOOP_DAMPED(st.w, st.Rh, st.ms, out.hi, out.lo, vv_next, ob_next, n, m0, m1, t2r, t2d);
+            else RSF_F32_TRIPS_LOOP_UNDAMPED(st.w, st.Rh, st.ms, out.hi, out.lo, vv_next, ob_next, n, m0, m1, t2r, t2d);
+            kk += NU * (n0 - n);
+            lt.incr += NU * (n0 - n);
+            if (n > 0) RSF_F32_TRIP_PRELOAD(lds_addr(lds + 2 * kk), lds_addr(ld + kk));
+          }
+        }
+        trip32<DAMP, NU>(st, lds + 2 * kk, ld, k0 + kk, kk, kk + 2 * NU <= kn, L, out, lt);
+        kk += NU;
+      }
     }
     int j = 2 * K.S * kk;
     for (; kk < kn; ++kk) {

@@ -5,7 +5,8 @@ one instantiation of mcmc_f32x2_kernel (no GPU needed) and checks, in its ISA, w
   * compiled code (everything outside the asm statements) touches no vector register at or above the private file's base;
   * the kernel uses no AGPR (with AGPRs in use amdgpu_num_vgpr would halve the architectural limit and move them);
   * no scratch access inside the trip loop (loop depth >= 3);
-  * every trip statement's packed instructions begin on an 8-byte boundary (the statement has its .p2align 3 behind the s_waitcnt).
+  * every packed instruction of every trip statement begins on an 8-byte boundary (the byte phase is followed through the
+    statement: .p2align 3 directives, 4-byte scalar instructions, 8-byte vector ones).
 
   python tools/check_private_file.py ['mcmc_f32x2_kernel<3, true, false>']        exit status 0 = all hold
 """
@@ -46,11 +47,20 @@ def main():
             continue
         if "#ASMEND" in l:
             inasm = False
-            if sum(b.startswith("v_pk_") for b in body) > 100:   # a trip statement: a 4-byte s_waitcnt, then .p2align 3, then 8-byte instructions only
+            if sum(b.startswith("v_pk_") for b in body) > 100:   # a trip statement: follow the byte phase of its instructions
                 trips += 1
-                k = next(j for j, b in enumerate(body) if b.startswith(".p2align"))
-                four = [b for b in body[k + 1:] if b.split()[0] in ("s_nop", "s_waitcnt") or b.endswith("_e32")]
-                misaligned += bool(four) or not body[k].startswith(".p2align 3")
+                phase, bad = None, 0                              # None: unknown until the first .p2align 3
+                for b in body:
+                    op = b.split()[0]
+                    if op == ".p2align":
+                        phase = 0 if b.split()[1] == "3" else None
+                    elif op.endswith(":"):
+                        pass
+                    elif op.startswith("s_") or op.endswith("_e32"):   # SOP* and VOP1/VOP2 encodings: 4 bytes
+                        phase = None if phase is None else phase ^ 4
+                    else:                                          # VOP3 / VOP3P / DS: 8 bytes
+                        bad += op.startswith("v_pk_") and phase != 0
+                misaligned += bad > 0
             continue
         code = l.split(";")[0].strip()
         if inasm:

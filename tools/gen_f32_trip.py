@@ -44,12 +44,15 @@ ISSUE = 4                              # cycles between two issues of one wave
 # trip is a packed-float one: a float64 or scalar instruction among them costs the wave ~8 cycles, tools/microbench_issue.hip).  Not measured latencies: a reader directly behind its producer costs one cycle (header), and with
 # these targets the scheduler keeps them apart wherever the dataflow offers something else to issue.
 LAT = {"pk": 10}
-COMPILER_VGPRS = 160                   # the sampler kernel is limited to v0..v159 (amdgpu_num_vgpr = half of this); the private file is v[160:255]
+COMPILER_VGPRS = 154                   # the sampler kernel is limited to v0..v153 (amdgpu_num_vgpr = half of this); the private file is v[154:255]
 PRIV0 = COMPILER_VGPRS
 CONSTS = ["hhd", "hd", "khh", "kh", "kh6", "boa", "nhboa", "kvk", "bh", "cv", "vref", "h6", "c16", "c13"]
 # in/out operands of the trip statement, in this order; then the two LDS byte addresses
 OPERANDS = ["w", "Rh", "ms", "s32", "g2r", "g2d"]
 ADDR_VV, ADDR_OB = len(OPERANDS), len(OPERANDS) + 1      # the NEXT trip's tables (prefetched while this trip computes)
+# the loop form (several trips in one statement): state and total in/out, the next trip's table addresses (advanced by the statement),
+# the count of trips left, two scalar temporaries; then the squared guard bounds
+LOOP_OPERANDS = ["w", "Rh", "ms", "hi", "lo", "vv_addr", "ob_addr", "n", "m0", "m1", "t2r", "t2d"]
 
 
 class Src:
@@ -206,6 +209,8 @@ class Regs:
         for c in CONSTS:
             self.const[c] = r
             r += 2
+        self.acc = {"s32": r, "g2r": r + 2, "g2d": r + 4}   # loop form: the group's sum of squares and the guard sums (halves compared in the statement)
+        r += 6
         self.vv = r          # 2 NU + 1 floats, base aligned to 4 registers for ds_read_b128
         assert self.vv % 4 == 0, "table base must be aligned for ds_read_b128"
         r += 2 * NU + 2
@@ -229,14 +234,19 @@ class Regs:
 def pair(r): return f"v[{r}:{r + 1}]"
 
 
-def emit_asm(order, by, final, regs):
+def emit_asm(order, by, final, regs, loop=False):
     last_use = {}
     for i, o in enumerate(order):
         for s in op_deps(o):
             last_use[s] = i
     for v in final.values():
         last_use[v] = len(order)
-    where = {name: f"%{i}" for i, name in enumerate(OPERANDS)}     # operands print as %N (register pairs)
+    names = LOOP_OPERANDS if loop else OPERANDS
+    where = {name: f"%{i}" for i, name in enumerate(names)}        # operands print as %N (register pairs)
+    if loop:                                                       # the accumulators of the loop form live in the private file
+        for k, r in regs.acc.items():
+            where[k] = pair(r)
+    a_vv, a_ob = (names.index("vv_addr"), names.index("ob_addr")) if loop else (ADDR_VV, ADDR_OB)
     phys = {}
     lines = []
     reads = []   # per line: the table registers it reads
@@ -295,14 +305,40 @@ def emit_asm(order, by, final, regs):
                 regs.free(phys.pop(s))
         if o.name not in last_use and o.name in phys:      # a result nobody reads (none expected)
             regs.free(phys.pop(o.name))
+    tail = []
+    if loop:
+        # The guard BEFORE anything is written back: on an alarm the statement is left with the state operands still holding the
+        # trip's start values (they are only written below) and the count operand telling which trip it was.
+        m0, m1, n = where["m0"], where["m1"], where["n"]
+        gr, gd = regs.acc["g2r"], regs.acc["g2d"]
+        tail += [f"v_cmp_nlt_f32_e64 {m0}, v{gr}, {where['t2r']}", f"v_cmp_nlt_f32_e64 {m1}, v{gr + 1}, {where['t2r']}", f"s_or_b64 {m0}, {m0}, {m1}",
+                 f"v_cmp_nlt_f32_e64 {m1}, v{gd}, {where['t2d']}", f"s_or_b64 {m0}, {m0}, {m1}",
+                 f"v_cmp_nlt_f32_e64 {m1}, v{gd + 1}, {where['t2d']}", f"s_or_b64 {m0}, {m0}, {m1}",
+                 f"s_and_b64 {m0}, {m0}, exec", "s_cbranch_scc1 .Lrsf_trips_exit_%=", ".p2align 3"]
     for k, v in final.items():
-        lines.append(f"v_pk_mov_b32 {where[k]}, {pair(phys[v])}, {pair(phys[v])} op_sel:[0,1]")
-        reads.append(set())
+        tail.append(f"v_pk_mov_b32 {where[k]}, {pair(phys[v])}, {pair(phys[v])} op_sel:[0,1]")
+    if loop:
+        # the group's sum into the total (hi, lo) by the exact two-sum (rsf_device_f32.h, Out32::flush)
+        x, hi, lo = where["s32"], where["hi"], where["lo"]
+        t = [pair(regs.alloc()) for _ in range(4)]
+        tail += [f"v_pk_add_f32 {t[0]}, {hi}, {x}",                                          # s = hi + x
+                 f"v_pk_add_f32 {t[1]}, {t[0]}, {hi} neg_lo:[0,1] neg_hi:[0,1]",               # bb = s - hi
+                 f"v_pk_add_f32 {t[2]}, {t[0]}, {t[1]} neg_lo:[0,1] neg_hi:[0,1]",             # t = s - bb
+                 f"v_pk_add_f32 {t[3]}, {x}, {t[1]} neg_lo:[0,1] neg_hi:[0,1]",                # e2 = x - bb
+                 f"v_pk_add_f32 {t[2]}, {hi}, {t[2]} neg_lo:[0,1] neg_hi:[0,1]",               # e1 = hi - t
+                 f"v_pk_mov_b32 {hi}, {t[0]}, {t[0]} op_sel:[0,1]",                            # hi = s
+                 f"v_pk_add_f32 {t[2]}, {t[2]}, {t[3]}",                                       # e1 + e2
+                 f"v_pk_add_f32 {lo}, {lo}, {t[2]}",                                           # lo += e
+                 f"v_add_u32_e64 {where['vv_addr']}, {where['vv_addr']}, {8 * NU}",            # the tables of the trip after the next
+                 f"v_add_u32_e64 {where['ob_addr']}, {where['ob_addr']}, {4 * NU}",
+                 f"s_sub_u32 {n}, {n}, 1", f"s_cmp_lg_u32 {n}, 0", "s_cbranch_scc1 .Lrsf_trips_loop_%="]
+    lines += tail
+    reads += [set()] * len(tail)
     if not PREFETCH:
-        return [l for l, _ in loads(regs, ADDR_VV, ADDR_OB)] + ["s_waitcnt lgkmcnt(0)", ".p2align 3"] + lines
+        return [l for l, _ in loads(regs, a_vv, a_ob)] + ["s_waitcnt lgkmcnt(0)", ".p2align 3"] + lines
     # the NEXT trip's table values: each load as soon as the registers it overwrites have been read for the last time
     out = list(zip(lines, reads))
-    for ins, dest in reversed(loads(regs, ADDR_VV, ADDR_OB)):
+    for ins, dest in reversed(loads(regs, a_vv, a_ob)):
         last = max((i for i, (_, rd) in enumerate(out) if rd & dest), default=-1)
         out.insert(last + 1, (ins, set()))
     return [l for l, _ in out]
@@ -373,6 +409,17 @@ def generate():
         out.append("  asm volatile( \\")
         out.append("\n".join(f'      "{l}\\n\\t" \\' for l in body))
         out.append('      : "+v"(w), "+v"(Rh), "+v"(ms), "=&v"(s32), "=&v"(g2r), "=&v"(g2d) : "v"(next_vv_addr), "v"(next_ob_addr) : "memory")')
+        out.append("")
+        # The loop form: `n` trips in ONE statement — what the compiled code does between two trips (the guard test, the group's sum
+        # into the total, addresses, loop control: ~60 instructions) shrinks to ~25 of its own.  It is left early, with `n` > 0 and
+        # the state of the failing trip's START, when a guard sum is not below its bound (the caller replays that trip step by
+        # step; the read-ahead has overwritten its tables: RSF_F32_TRIP_PRELOAD first).  Only for waves without a full-evaluation chain.
+        regs = Regs()
+        body = emit_asm(order, by, final, regs, loop=True)
+        out.append(f"#define RSF_F32_TRIPS_LOOP_{tag}(w, Rh, ms, hi, lo, next_vv_addr, next_ob_addr, n, m0, m1, t2r, t2d) \\")
+        out.append("  asm volatile( \\")
+        out.append("\n".join(f'      "{l}\\n\\t" \\' for l in [".p2align 3", ".Lrsf_trips_loop_%=:", "s_waitcnt lgkmcnt(0)", ".p2align 3"] + body + [".Lrsf_trips_exit_%=:"]))
+        out.append('      : "+v"(w), "+v"(Rh), "+v"(ms), "+v"(hi), "+v"(lo), "+v"(next_vv_addr), "+v"(next_ob_addr), "+s"(n), "=&s"(m0), "=&s"(m1) : "s"(t2r), "s"(t2d) : "memory", "scc")')
         out.append("")
     return "\n".join(out), report
 
