@@ -182,7 +182,7 @@ def test_generated_trip_is_current():
 
 
 def test_float32_trip_owns_its_private_register_file():
-    """The float32 sampler's assembly trip keeps constants, tables and temporaries in v[160:255] across statements.  That is
+    """The float32 sampler's assembly trip keeps constants, tables and temporaries in the registers above RSF_F32_TRIP_COMPILER_VGPRS (v[154:255]) across statements.  That is
     sound only while compiled code never touches those registers, the kernel uses no AGPR, nothing spills inside the trip loop
     and the trip's 8-byte instruction stream starts on an 8-byte boundary: tools/check_private_file.py compiles one
     instantiation (no GPU) and checks all four in the ISA."""
