@@ -1027,8 +1027,8 @@ def test_float32_sampler_is_exact_at_config5_shape(pkg, oracle_mod):
 
 def test_float32_tolerance_at_config5_shape():
     """BASELINE configs[4] per-GPU shard (131 072 chains, nsteps 4000, joint (Dc, a, b)) in BOTH precisions, same seeds —
-    tools/fp32_sweep_cfg5.py with a shorter sampler run.  Bands (profiles/r02/fp32_sweep_cfg5.json holds the 400-iteration
-    numbers): relative |SSq32 - SSq64| <= 1e-3 on every lane; posterior mean / std of each parameter move by less than
+    tools/fp32_sweep_cfg5.py with a shorter sampler run.  Bands (profiles/r04/fp32_sweep_cfg5.json holds the 400-iteration
+    numbers): relative |SSq32 - SSq64| <= 1e-4 on every lane (median <= 1e-6); posterior mean / std of each parameter move by less than
     0.02 / 0.02 float64 posterior standard deviations; acceptance rates within 0.01."""
     import os
     import sys
@@ -1039,7 +1039,8 @@ def test_float32_tolerance_at_config5_shape():
     out = fp32_sweep_cfg5.sweep(iters=60)
     assert out["shape"] == {"chains": 131072, "nsteps": 4000, "n_params": 3, "iters": 60}
     assert out["ssq"]["nonfinite_f64"] == out["ssq"]["nonfinite_f32"] == 0 and out["ssq"]["lanes"] == 131072
-    assert out["ssq"]["rel_max"] < 1e-3 and out["ssq"]["rel_median"] < 2e-5, out["ssq"]
+    # (round 4, incremental float32 step: measured 2.6e-5 / 1.0e-7 — profiles/r04/fp32_sweep_cfg5.json; until then 1.2e-4 / 1.7e-6)
+    assert out["ssq"]["rel_max"] < 1e-4 and out["ssq"]["rel_median"] < 1e-6, out["ssq"]
     post = out["posterior"]
     assert max(post["drift_in_units_of_f64_posterior_std"]["mean"]) < 0.02, post
     assert max(post["drift_in_units_of_f64_posterior_std"]["std"]) < 0.02, post
