@@ -1,7 +1,7 @@
 // rsf_device_f32.h — float32 forward solve (BASELINE config 5: "float32 vs float64 tolerance sweep").
 //
-// Selected per model with RSF_FLAG_FP32_SOLVE.  Only the ODE integration runs in float32; every
-// interface array, the sum of squares accumulator and the whole sampler logic (proposal, accept
+// Selected per model with RSF_FLAG_FP32_SOLVE.  The ODE integration and the summation of squared residuals run in float32
+// (the latter in a way that keeps ~48 bits, Out32); every interface array and the whole sampler logic (proposal, accept
 // test, sigma^2 update, adaptation, initial covariance) stay float64.
 //
 // Same rescaled state as the float64 path — ms = mu/k', x = V_ref theta/Dc — and the same regrouping of the RHS around
@@ -14,8 +14,9 @@
 //   * It starts in the INCREMENTAL form (round 4; rk4_incr): the state is (w, Rh = (h/2Dc)/x), ms rides along, and every
 //     stage of an RK4 step reaches its (w, 1/x) from the step's start point by short series — log1p to rho^2/2, expm1 to
 //     dlt^3/6, 1/x' = (1/x)(1 - rho + rho^2) — the float64 TIGHT tier's step (rsf_device.h, rk4_tight) with one expm1 term
-//     fewer and the operations ordered for a short dependency chain (incr): NO transcendental instruction.  (Until round 4 every stage was a full evaluation with v_log_f32 / v_exp_f32 /
-//     v_rcp_f32 — 12 per chain-step at half rate, a third of the step's issue cycles.)  In float32 the series are good
+//     fewer and the operations ordered for a short dependency chain (incr): NO transcendental instruction.  (Until round 4
+//     every stage was a full evaluation with v_log_f32 / v_exp_f32 / v_rcp_f32 — 12 per chain-step at half rate, a third
+//     of the step's issue cycles.)  In float32 the series are good
 //     to < 1e-9 relative for |rho| < 2^-9, |dlt| < 2^-6: one tier reaches further than the float64 path's three.
 //   * A step whose END increments leave |rho| < 2^-10, |dlt| < 2^-7 (a factor of two inside the series' range, for the
 //     stages of the step, whose increments are of the end increments' size) is not taken incrementally: from that step
@@ -216,10 +217,11 @@ __device__ __forceinline__ void rhs_incr(V w, V xr, V Rh, V vl2, V brx, const La
 
 // (w', 1 + q = x/x') at the point reached from the step's start point (w0, x) by rho = dx/x and d(mu)/a = kd d0:
 //   dlt = kd d0 - (b/a) log1p(rho),  w' = w0 exp(dlt),  1/x' = (1/x)(1 + q)
-// written for a SHORT DEPENDENCY CHAIN, not for few operations: at one wave per SIMD (config 5's shape) a dependent packed
-// instruction issues 9.7 cycles after its producer, an independent one after 4 (tools/microbench_pk_f32.hip), and d0 — the
-// damped d(ms)/dt — is the last value of a stage to arrive.  rho P is formed beside it, so dlt is ONE operation after d0;
-// w' = w0 (1 + dlt) + dlt^2 (w0/2 + (w0/6) dlt) is two levels after dlt (Horner: three).  w02 = w0/2, w06 = w0/6: per step.
+// written for a SHORT DEPENDENCY CHAIN at equal operation count — d0, the damped d(ms)/dt, is the last value of a stage to arrive:
+// rho P is formed beside it, so dlt is ONE operation after d0; w' = w0 (1 + dlt) + dlt^2 (w0/2 + (w0/6) dlt) is two levels after
+// dlt (Horner: three); w02 = w0/2, w06 = w0/6 once per step.  25 dependent levels per step instead of 33: the scheduler of the
+// generated trip (tools/gen_f32_trip.py) then always has something to issue that does not read the instruction before it (a
+// reader directly behind its producer costs a cycle, and in hipcc's own code a wait state: tools/microbench_issue.hip).
 template <typename V>
 __device__ __forceinline__ void incr(V rho, V kd, V d0, const LaneV<V> &L, V w0, V w02, V w06, V &w, V &q, V &dlt) {
 #pragma clang fp contract(off)

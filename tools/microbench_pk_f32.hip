@@ -6,7 +6,9 @@
 // the float32 solve is one long dependent chain, so that is one issue slot in five.  Kernel 0 is the compiler's form
 // (with the nops; one asm statement per instruction, kernel 1, gets them too: the recogniser treats an asm result alike),
 // kernel 2 the same chain as ONE asm block with nothing between the dependent instructions.  If the results are bit-identical over many
-// chains and lengths, the hardware needs no wait state there; the times give what the nops cost.
+// chains and lengths, the hardware needs no wait state there; the DIFFERENCE of the times gives what the nops cost (4 cycles each).
+// (The absolute "cycles per packed op" this program prints include the loop branch of an 8-instruction body — they are not
+// instruction costs; tools/microbench_issue.hip measures those with long straight-line bodies and the shader clock.)
 //
 //   hipcc -O3 --offload-arch=gfx950 -o build/microbench_pk_f32 tools/microbench_pk_f32.hip && build/microbench_pk_f32
 #include <hip/hip_runtime.h>
