@@ -72,6 +72,7 @@ struct rsf_ctx {
   int32_t nout = 0;
   double delta_t = 0, h = 0;
   int32_t kc = 0, nchunks = 0;
+  int32_t kc32 = 0, nchunks32 = 0;  // the float32 SAMPLER's own chunking: its tables are floats, twice as many fit the budget
   size_t lds_bytes = 0;
   DevBuf vl;
   // chains
@@ -186,10 +187,20 @@ int chains_per_lane(const rsf_ctx *c) { return mode_of(c) == RK4_F32 ? 2 : 1; }
 
 // LDS of a sampler launch: the table chunk, and behind it the per-lane Cholesky factors of a three-parameter chain
 // (six doubles per lane, mcmc_kernel)
-// the table chunk as the sampler kernel stages it: doubles, or floats in the float32 sampler (same chunk length kc: the
-// float64 init kernel of that mode stages the same chunks as doubles)
+// the table chunk as the sampler kernel stages it: doubles, or floats in the float32 sampler — with a chunk length of its own
+// (kc32, rsf_set_model): nsteps 4000 is ONE chunk of 48 KB there, resident for the whole launch, where the shared length kc
+// (sized for doubles) made it two, staged — with two workgroup barriers each — for every proposal
 size_t mcmc_table_bytes(const rsf_ctx *c) {
-  return mode_of(c) == RK4_F32 ? ((c->lds_bytes / 2 + 15) & ~(size_t)15) : c->lds_bytes;
+  if (mode_of(c) != RK4_F32) return c->lds_bytes;
+  const size_t floats = 2 * (size_t)c->m.substeps * (size_t)c->kc32 + 1 + (size_t)c->kc32 + 1;
+  return (floats * sizeof(float) + 15) & ~(size_t)15;
+}
+
+// the sampler's kernel constants: make_consts with the chunking the sampler kernel of this mode uses
+Consts make_sampler_consts(const rsf_ctx *c, const double *data) {
+  Consts K = make_consts(c, data);
+  if (mode_of(c) == RK4_F32) { K.kc = c->kc32; K.nchunks = c->nchunks32; }
+  return K;
 }
 
 size_t mcmc_lds_bytes(const rsf_ctx *c) {
@@ -428,7 +439,7 @@ int run_mcmc(rsf_ctx *c, int64_t n_iters, const double *z, const double *u, cons
   A.stats = (unsigned long long *)c->stats.p;
   int rc;
   if (replay && !ssq_new && host_mem(c) && n_iters == 1 && C <= kReplayGraphMaxChains) {
-    Consts Kg = make_consts(c, (const double *)c->data.p);
+    Consts Kg = make_sampler_consts(c, (const double *)c->data.p);
     Kg.group_chains = c->group_chains;
     return run_replay_graph(c, Kg, A, z, u, g, tq, ts, ta);
   }
@@ -441,7 +452,7 @@ int run_mcmc(rsf_ctx *c, int64_t n_iters, const double *z, const double *u, cons
   const void *dsn = nullptr;
   if ((rc = stage_in(c, 6, ssq_new, rows * sizeof(double), &dsn))) return rc;
   A.ssq_new = (const double *)dsn;
-  Consts K = make_consts(c, (const double *)c->data.p);
+  Consts K = make_sampler_consts(c, (const double *)c->data.p);
   K.group_chains = c->group_chains;
   if (host_mem(c) && !replay) {
     const size_t row_bytes = (size_t)C * ((tq ? d * sizeof(double) : 0) + (ts ? sizeof(double) : 0) + (ta ? 1 : 0));
@@ -655,6 +666,15 @@ int rsf_set_model(rsf_ctx *c, const rsf_model *m) {
   c->delta_t = delta_t; c->h = h; c->nout = nout;
   c->kc = (int32_t)kc;
   c->nchunks = (int32_t)((nout - 1 + kc - 1) / kc);
+  c->kc32 = c->kc; c->nchunks32 = c->nchunks;
+  if ((m->flags & RSF_FLAG_FP32_SOLVE) && !dop) {
+    // the float32 sampler stages floats: the same budget in bytes holds twice the entries (chunks on a group boundary, as above)
+    int64_t k32 = ((int64_t)(kLdsBudget / sizeof(float)) - 2) / (2 * (int64_t)S + 1);
+    if (k32 > nout - 1) k32 = nout - 1;
+    if (k32 < nout - 1 && k32 >= 8) k32 &= ~(int64_t)7;
+    c->kc32 = (int32_t)k32;
+    c->nchunks32 = (int32_t)((nout - 1 + k32 - 1) / k32);
+  }
   c->lds_bytes = (size_t)((dop ? rsf::dp::kTab * kc : 2 * S * kc + 1) + kc + 1 + 2 * rsf::kLdsPad) * sizeof(double);
   c->have_model = true;
   return RSF_OK;

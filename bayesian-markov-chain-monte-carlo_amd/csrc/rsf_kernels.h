@@ -43,8 +43,8 @@ constexpr int kD3Trip = 2;
 // LDS per workgroup for the loading table + observation chunk.  Two workgroups per CU (kMinBlocks) at 56 KiB each fit the
 // CU's 160 KiB next to the samplers' per-lane slots (up to 24 KiB: Cholesky factors, parked chain state); nsteps 2000
 // (48 KB) stays resident for the whole launch instead of being staged twice per proposal (+1.3 % at cfg2).  The chunk LENGTH
-// kc is sized once, for tables of doubles (rsf_set_model): the float32 sampler stages the same chunks as floats — half the
-// bytes, but nsteps 4000 is two chunks in that mode too, because its float64 init kernel shares the chunking.
+// kc is sized for tables of doubles (rsf_set_model); the float32 SAMPLER, whose tables are floats, has its own (kc32: nsteps
+// 4000 is one resident chunk of 48 KB there), the other float32 kernels share kc with the float64 init kernel of that mode.
 constexpr size_t kLdsBudget = 56 * 1024;
 // per-lane LDS slots (doubles) of the float64 RK4 sampler behind the table chunk: D = 3: the Cholesky factor's six; then the
 // chain's point, sigma^2, SSq and log u parked across the forward solve (mcmc_kernel)
