@@ -1000,6 +1000,41 @@ def test_float32_step_forms_mixed_in_one_wave(pkg, oracle_lib, oracle_mod, dampi
     np.testing.assert_allclose(tg[0][:, same], tc[0][:, same], rtol=1e-9)
 
 
+@pytest.mark.parametrize("d", [1, 3])
+def test_float32_replay_of_given_variates(pkg, oracle_lib, oracle_mod, d):
+    """The float32 sampler fed its variates by the caller (rsf_mcmc_replay: the REPLAY instantiation of mcmc_f32x2_kernel, which
+    the public sub-methods run on) — the same assembly trip, the chain logic on replayed normals, uniforms and gamma variates:
+    against the restatement replaying the same variates every decision is the same and the samples agree to 1e-9, chain counts
+    that leave a lane's second slot empty, one iteration at a time as well as in one call."""
+    m = _models(oracle_mod, 500)
+    m.precision = "float32"
+    rng = np.random.default_rng(33 + d)
+    C, n = 333, 9
+    z, u, g = rng.standard_normal((n, C, d)), rng.uniform(size=(n, C)), rng.gamma(250.005, size=(n, C))
+    q0 = np.column_stack([rng.uniform(600.0, 2000.0, C), rng.uniform(0.010, 0.012, C), rng.uniform(0.013, 0.015, C)])[:, :d]
+    lo, hi = [0.0, 0.005, 0.005][:d], [1.0e4, 0.02, 0.03][:d]
+    V0 = np.tile(np.diag(np.array([25.0 ** 2, 1e-4 ** 2, 1e-4 ** 2][:d])), (C, 1, 1))
+    with pkg.Engine(mem="host") as gpu, pkg.Engine(lib=oracle_lib) as cpu, pkg.Engine(lib=oracle_lib) as c64:
+        c64.set_model(_models(oracle_mod, 500), 1)
+        data = synthetic_data(c64)
+        for e in (gpu, cpu):
+            e.set_model(m, 1)
+            e.mcmc_init(q0, data, lo, hi, seed=1, prior_len=3 if d == 1 else 0, adapt_mode="none")
+        st = list(cpu.get_state())
+        st[3] = V0
+        for e in (gpu, cpu):
+            e.set_state(*st)
+        tg, tc = gpu.mcmc_replay(z, u, g), cpu.mcmc_replay(z, u, g)
+        np.testing.assert_array_equal(tg[2], tc[2])
+        np.testing.assert_allclose(tg[0], tc[0], rtol=1e-9)
+        np.testing.assert_allclose(tg[1], tc[1], rtol=1e-6)
+        assert 0.05 < tg[2].mean() < 0.98
+        gpu.set_state(*st)           # the same again, one iteration per call (the hipGraph path of a one-proposal replay)
+        rows = [gpu.mcmc_replay(z[k:k + 1], u[k:k + 1], g[k:k + 1]) for k in range(n)]
+        np.testing.assert_array_equal(np.concatenate([r[0] for r in rows]), tg[0])
+        np.testing.assert_array_equal(np.concatenate([r[2] for r in rows]), tg[2])
+
+
 def test_float32_sampler_is_exact_at_config5_shape(pkg, oracle_mod):
     """The packed two-chains-per-lane solve at BASELINE configs[4]'s own per-GPU shape (131 072 chains, nsteps 4000, joint
     (Dc, a, b): two LDS chunks per solve): after three proposals every chain's SSq is bit-identical to the one-chain float32
