@@ -1000,13 +1000,14 @@ def test_float32_step_forms_mixed_in_one_wave(pkg, oracle_lib, oracle_mod, dampi
     np.testing.assert_allclose(tg[0][:, same], tc[0][:, same], rtol=1e-9)
 
 
-@pytest.mark.parametrize("d", [1, 3])
-def test_float32_replay_of_given_variates(pkg, oracle_lib, oracle_mod, d):
+@pytest.mark.parametrize("d,substeps", [(1, 1), (3, 1), (1, 2)])
+def test_float32_replay_of_given_variates(pkg, oracle_lib, oracle_mod, d, substeps):
     """The float32 sampler fed its variates by the caller (rsf_mcmc_replay: the REPLAY instantiation of mcmc_f32x2_kernel, which
     the public sub-methods run on) — the same assembly trip, the chain logic on replayed normals, uniforms and gamma variates:
     against the restatement replaying the same variates every decision is the same and the samples agree to 1e-9, chain counts
-    that leave a lane's second slot empty, one iteration at a time as well as in one call."""
-    m = _models(oracle_mod, 500)
+    that leave a lane's second slot empty, one iteration at a time as well as in one call.  With two RK4 steps per output
+    interval no step belongs to a trip: the two-chain form goes step by step throughout (step_any, compiled code)."""
+    m = _models(oracle_mod, 500, substeps)
     m.precision = "float32"
     rng = np.random.default_rng(33 + d)
     C, n = 333, 9
@@ -1015,10 +1016,10 @@ def test_float32_replay_of_given_variates(pkg, oracle_lib, oracle_mod, d):
     lo, hi = [0.0, 0.005, 0.005][:d], [1.0e4, 0.02, 0.03][:d]
     V0 = np.tile(np.diag(np.array([25.0 ** 2, 1e-4 ** 2, 1e-4 ** 2][:d])), (C, 1, 1))
     with pkg.Engine(mem="host") as gpu, pkg.Engine(lib=oracle_lib) as cpu, pkg.Engine(lib=oracle_lib) as c64:
-        c64.set_model(_models(oracle_mod, 500), 1)
+        c64.set_model(_models(oracle_mod, 500, substeps), substeps)
         data = synthetic_data(c64)
         for e in (gpu, cpu):
-            e.set_model(m, 1)
+            e.set_model(m, substeps)
             e.mcmc_init(q0, data, lo, hi, seed=1, prior_len=3 if d == 1 else 0, adapt_mode="none")
         st = list(cpu.get_state())
         st[3] = V0
