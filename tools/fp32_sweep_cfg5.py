@@ -7,8 +7,9 @@
 1. sum of squares: 131 072 lanes with (Dc, a, b) drawn inside the prior box, float32 solve vs float64 solve of the same
    lanes → max / median relative |SSq32 - SSq64|;
 2. sampler: 131 072 three-parameter chains x `iters` proposals in both precisions with identical Philox seeds (adaptive
-   Metropolis, explicit start covariance) → posterior mean / std drift in units of the float64 posterior std, acceptance
-   rates, and the throughput of both runs (ODE-steps x chains / s).
+   Metropolis, the init kernel's own start covariance) → posterior mean / std drift in units of the float64 posterior std,
+   acceptance rates, and the throughput of both runs (ODE-steps x chains / s) — once with every chain started at the truth,
+   once with the chains started away from it, dispersed over the prior box.
 tests/test_gpu_parity.py::test_float32_tolerance_at_config5_shape asserts the bands on a shorter run of the same code."""
 import json
 import os
@@ -53,8 +54,19 @@ def sweep(iters=400, chains=CHAINS, nsteps=NSTEPS, seed=9):
     rel = np.abs(ssq["float32"][fin] - ssq["float64"][fin]) / ssq["float64"][fin]
     out["ssq"] = {"lanes": int(fin.sum()), "nonfinite_f64": int((~fin).sum()), "nonfinite_f32": int((~np.isfinite(ssq["float32"])).sum()),
                   "rel_max": float(rel.max()), "rel_p999": float(np.quantile(rel, 0.999)), "rel_median": float(np.median(rel))}
+    out["posterior"] = sampler_leg(pkg, torch, m, d_dev, chains, nsteps, iters, seed,
+                                   torch.tensor([1000.0, 0.011, 0.014], dtype=torch.float64, device="cuda").repeat(chains, 1))
+    # the same with chains started AWAY from the truth, dispersed over the box (the same points in both precisions): the two
+    # precisions must also agree while the chains travel and the adaptive proposal forms
+    r2 = np.random.default_rng(77)
+    a0 = r2.uniform(0.008, 0.016, chains)
+    q0d = np.column_stack([r2.uniform(300.0, 3000.0, chains), a0, a0 + r2.uniform(0.0, 0.008, chains)])
+    out["posterior_dispersed_starts"] = sampler_leg(pkg, torch, m, d_dev, chains, nsteps, iters, seed, torch.as_tensor(q0d).cuda())
+    return out
+
+
+def sampler_leg(pkg, torch, m, d_dev, chains, nsteps, iters, seed, q0):
     res = {}
-    q0 = torch.tensor([1000.0, 0.011, 0.014], dtype=torch.float64, device="cuda").repeat(chains, 1)
     for p in ("float64", "float32"):
         with pkg.Engine(mem="device") as e:
             e.set_model(m[p], 1)
@@ -74,10 +86,9 @@ def sweep(iters=400, chains=CHAINS, nsteps=NSTEPS, seed=9):
             torch.cuda.empty_cache()
     drift = {k: (np.abs(np.array(res["float32"][k]) - np.array(res["float64"][k])) / np.array(res["float64"]["std"])).tolist()
              for k in ("mean", "std")}
-    out["posterior"] = dict(res, drift_in_units_of_f64_posterior_std=drift,
-                            accept_diff=abs(res["float32"]["accept"] - res["float64"]["accept"]),
-                            speedup_f32=res["float32"]["ode_steps_x_chains_per_s"] / res["float64"]["ode_steps_x_chains_per_s"])
-    return out
+    return dict(res, drift_in_units_of_f64_posterior_std=drift,
+                accept_diff=abs(res["float32"]["accept"] - res["float64"]["accept"]),
+                speedup_f32=res["float32"]["ode_steps_x_chains_per_s"] / res["float64"]["ode_steps_x_chains_per_s"])
 
 
 if __name__ == "__main__":
